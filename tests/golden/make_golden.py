@@ -1,0 +1,388 @@
+#!/usr/bin/env python3
+"""Generate the golden vectors under tests/golden/ by EXECUTING the reference's
+own ``active_gym/fov_env.py`` and ``active_gym/atari_env.py`` (read from
+/root/reference, never copied) in the build container.
+
+The reference imports four third-party modules that are absent from the image
+(cv2, gymnasium, torchvision, atari_py).  They are replaced *for this script
+only* by minimal stand-ins pre-seeded into ``sys.modules``:
+
+* ``gymnasium``  — ``Env``, ``Wrapper`` (attribute forwarding), ``spaces.Box /
+  Discrete / Dict`` as plain data holders.  No arithmetic.
+* ``torchvision.transforms.Resize(size)`` — unsqueeze -> ``torch.nn.functional.
+  interpolate(size, mode="bilinear", align_corners=False, antialias=A)`` ->
+  squeeze, with torchvision's same-size early return.  That IS the backend of
+  torchvision's tensor path and torch is in the image; ``A`` (version
+  dependent default) is emitted both ways.
+* ``cv2`` — ``resize`` = identity on an already obs-sized screen.  The atari
+  goldens therefore pin the reference's CONTROL FLOW only (frame sampling at
+  t==2/3, zero fill, max, deque order, life-loss, resets, reward bookkeeping);
+  OpenCV's fixed-point arithmetic stays "parity unpinned".
+* ``atari_py`` — ``tests/fake_ale.ScriptedALE`` (an event script, not an emulator).
+
+Only data (inputs + the reference's outputs) is written; run from the repo root:
+    python tests/golden/make_golden.py
+"""
+from __future__ import annotations
+
+import importlib.util
+import os
+import random
+import sys
+import types
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+REPO = os.path.dirname(os.path.dirname(HERE))
+REF = os.environ.get("AGX_REFERENCE", "/root/reference")
+sys.path.insert(0, os.path.join(REPO, "tests"))
+from fake_ale import ScriptedALE  # noqa: E402
+
+_STATE = {"antialias": True, "next_ale": None}
+
+
+# ------------------------------------------------------------------ stand-ins
+def _install_standins():
+    # gymnasium
+    gym = types.ModuleType("gymnasium")
+
+    class Env:
+        pass
+
+    class Wrapper(Env):
+        def __init__(self, env):
+            self.env = env
+
+        def __getattr__(self, name):
+            if name.startswith("__") or name == "env":
+                raise AttributeError(name)
+            return getattr(self.env, name)
+
+    class Box:
+        def __init__(self, low, high, shape=None, dtype=np.float32):
+            self.low, self.high, self.shape, self.dtype = low, high, shape, dtype
+
+    class Discrete:
+        def __init__(self, n):
+            self.n = n
+
+        def sample(self):
+            return random.randrange(self.n)
+
+    class Dict(dict):
+        def __init__(self, d):
+            super().__init__(d)
+
+    spaces = types.ModuleType("gymnasium.spaces")
+    spaces.Box, spaces.Discrete, spaces.Dict = Box, Discrete, Dict
+    gym.Env, gym.Wrapper, gym.spaces = Env, Wrapper, spaces
+    sys.modules["gymnasium"] = gym
+    sys.modules["gymnasium.spaces"] = spaces
+
+    # torchvision.transforms.Resize
+    tv = types.ModuleType("torchvision")
+    tvt = types.ModuleType("torchvision.transforms")
+
+    class Resize(torch.nn.Module):
+        def __init__(self, size):
+            super().__init__()
+            self.size = tuple(int(s) for s in size)
+
+        def forward(self, img):
+            if tuple(img.shape[-2:]) == self.size:
+                return img
+            out = torch.nn.functional.interpolate(
+                img.unsqueeze(0), size=self.size, mode="bilinear",
+                align_corners=False, antialias=_STATE["antialias"])
+            return out.squeeze(0)
+
+    tvt.Resize = Resize
+    tv.transforms = tvt
+    sys.modules["torchvision"] = tv
+    sys.modules["torchvision.transforms"] = tvt
+
+    # cv2
+    cv2 = types.ModuleType("cv2")
+    cv2.INTER_LINEAR = 1
+
+    def resize(img, dsize, interpolation=None):
+        img = np.asarray(img)
+        if img.ndim == 3 and img.shape[-1] == 1:
+            img = img[..., 0]
+        assert img.shape == (dsize[1], dsize[0]), (img.shape, dsize)
+        return img.copy()
+
+    cv2.resize = resize
+    sys.modules["cv2"] = cv2
+
+    # atari_py
+    ap = types.ModuleType("atari_py")
+    ap.ALEInterface = lambda: _STATE["next_ale"]
+    ap.get_game_path = lambda game: game
+    sys.modules["atari_py"] = ap
+
+
+def _load_reference():
+    pkg = types.ModuleType("refpkg")
+    pkg.__path__ = [os.path.join(REF, "active_gym")]
+    sys.modules["refpkg"] = pkg
+    mods = {}
+    for name in ("fov_env", "atari_env"):
+        spec = importlib.util.spec_from_file_location(
+            f"refpkg.{name}", os.path.join(REF, "active_gym", f"{name}.py"))
+        m = importlib.util.module_from_spec(spec)
+        sys.modules[f"refpkg.{name}"] = m
+        spec.loader.exec_module(m)
+        mods[name] = m
+    return mods["fov_env"], mods["atari_env"]
+
+
+# ------------------------------------------------------------------ fovea goldens
+class _Args:
+    def __init__(self, **kw):
+        self.record = False
+        self.mask_out = False
+        for k, v in kw.items():
+            setattr(self, k, v)
+
+
+def _make_states(rng, steps, fs, obs):
+    """u8 numerators; reference sees float64 holding float32(k)/255."""
+    return rng.integers(0, 256, size=(steps + 1, fs) + tuple(obs), dtype=np.uint8)
+
+
+def _unit(u8):
+    return (u8.astype(np.float32) / np.float32(255.0)).astype(np.float64)
+
+
+def _fovea_case(fov_env, gym, kind, name, obs, fov, fs, mode, resize_to_full, mask_out,
+                antialias, steps, seed, per=None, init_loc=(0, 0), sas=(-10.0, 10.0),
+                out_dtype=np.float32, int_actions=False):
+    rng = np.random.default_rng(seed)
+    states_u8 = _make_states(rng, steps, fs, obs)
+    _STATE["antialias"] = antialias
+
+    class FakeBase(gym.Env):
+        def __init__(self):
+            self.obs_size = tuple(obs)
+            self.frame_stack = fs
+            self.action_space = gym.spaces.Discrete(4)
+            self.t = 0
+
+        def reset(self, seed=None, options=None):
+            self.t = 0
+            return _unit(states_u8[0]), {"raw_reward": 0}
+
+        def step(self, action):
+            self.t += 1
+            return _unit(states_u8[self.t]), 1.0, False, False, {"raw_reward": 1.0}
+
+        def render(self):
+            return None
+
+    args = _Args(fov_size=tuple(fov), fov_init_loc=tuple(init_loc), sensory_action_mode=mode,
+                 sensory_action_space=sas, resize_to_full=resize_to_full, mask_out=mask_out,
+                 peripheral_res=per)
+    base = fov_env.RecordWrapper(FakeBase(), args)
+    cls = {"fixed": fov_env.FixedFovealEnv, "flex": fov_env.FlexibleFovealEnv,
+           "per": fov_env.FixedFovealPeripheralEnv}[kind]
+    env = cls(base, args)
+
+    hi = np.array(obs) - np.array(fov)
+    actions, types_, outs, locs, ress = [], [], [], [], []
+    o, info = env.reset()
+    outs.append(np.asarray(o))
+    locs.append(info["fov_loc"].copy())
+    ress.append(np.asarray(info.get("fov_res", fov)).copy())
+    cur_res = np.array(fov)
+    for t in range(steps):
+        atype = 0
+        if kind == "flex" and rng.random() < 0.5:
+            atype = 1
+            # integer resolutions in [6, obs]: rows above and below fov rows, cols independent
+            a = np.array([rng.integers(6, obs[0] + 1), rng.integers(6, obs[1] + 1)])
+            if t == 1:
+                a = np.array([fov[0] + 7, max(6, fov[1] - 5)])     # rows > fov rows, cols < fov cols
+            if t == 3:
+                a = np.array([obs[0], obs[1]])                     # full-frame window
+        elif mode == "absolute":
+            a = rng.uniform(-5.0, max(hi) + 6.0, size=2)
+            if t % 3 == 1:
+                a = np.floor(a) + 0.5                              # exercise round-half-even
+            if int_actions:
+                a = np.rint(a).astype(np.int64)
+        else:
+            a = rng.uniform(sas[0] - 4.0, sas[1] + 4.0, size=2)
+            if t % 3 == 1:
+                a = np.floor(a) + 0.5
+        act = {"motor_action": 0, "sensory_action": a}
+        if kind == "flex":
+            act["sensory_action_type"] = np.array((atype,))
+        o, r, d, tr, info = env.step(act)
+        actions.append(np.asarray(a, dtype=np.float64))
+        types_.append(atype)
+        outs.append(np.asarray(o))
+        locs.append(np.asarray(info["fov_loc"]).copy())
+        ress.append(np.asarray(info.get("fov_res", fov)).copy())
+        assert info["ep_len"] == t + 1 and info["reward"] == float(t + 1)
+    rec = {
+        "kind": kind, "obs_size": np.array(obs), "fov_size": np.array(fov), "frame_stack": fs,
+        "mode": mode, "resize_to_full": resize_to_full, "mask_out": mask_out, "antialias": antialias,
+        "peripheral_res": np.array(per if per else (0, 0)), "init_loc": np.array(init_loc),
+        "sas": np.array(sas, dtype=np.float64), "states_u8": states_u8,
+        "actions": np.array(actions), "action_types": np.array(types_, dtype=np.int64),
+        "fov_loc": np.array(locs, dtype=np.int64), "fov_res": np.array(ress, dtype=np.int64),
+        "out_f64_dtype": str(outs[0].dtype),
+    }
+    assert all(x.dtype == np.float64 for x in outs), "reference emits float64 (SURVEY §8a-Q1)"
+    ragged = len({x.shape for x in outs}) > 1
+    rec["ragged"] = ragged
+    if ragged:
+        for i, x in enumerate(outs):
+            rec[f"out_{i}"] = x.astype(out_dtype)
+    else:
+        rec["out"] = np.stack(outs).astype(out_dtype)
+    path = os.path.join(HERE, f"fovea_{name}.npz")
+    np.savez_compressed(path, **rec)
+    return path
+
+
+def make_fovea(fov_env, gym):
+    paths = []
+    n = 0
+    std = dict(obs=(84, 84), fov=(30, 30))
+    for mode in ("absolute", "relative"):
+        for tag, rtf, mo in (("resize", True, False), ("mask", False, True), ("raw", False, False)):
+            n += 1
+            paths.append(_fovea_case(fov_env, gym, "fixed", f"fixed_{tag}_{mode[:3]}", fs=2, mode=mode,
+                                     resize_to_full=rtf, mask_out=mo, antialias=True, steps=5,
+                                     seed=100 + n, init_loc=(10.4, 20.5), **std))
+    # the headline config verbatim (fs=4), antialias off (== on for upscaling), int actions
+    paths.append(_fovea_case(fov_env, gym, "fixed", "fixed_resize_abs_fs4_aa0", fs=4, mode="absolute",
+                             resize_to_full=True, mask_out=False, antialias=False, steps=3, seed=200,
+                             int_actions=True, **std))
+    # mask_out wins over resize_to_full (fov_env.py:176-183)
+    paths.append(_fovea_case(fov_env, gym, "fixed", "fixed_maskwins_abs", fs=2, mode="absolute",
+                             resize_to_full=True, mask_out=True, antialias=True, steps=3, seed=201, **std))
+    for aa in (False, True):
+        paths.append(_fovea_case(fov_env, gym, "per", f"per_aa{int(aa)}", fs=2, mode="absolute",
+                                 resize_to_full=False, mask_out=True, antialias=aa, steps=4, seed=300 + aa,
+                                 per=(20, 20), **std))
+        for tag, rtf, mo in (("resize", True, False), ("mask", False, True), ("raw", False, False)):
+            paths.append(_fovea_case(fov_env, gym, "flex", f"flex_{tag}_aa{int(aa)}", fs=2, mode="absolute",
+                                     resize_to_full=rtf, mask_out=mo, antialias=aa, steps=8,
+                                     seed=400 + 10 * aa + len(tag), **std))
+    paths.append(_fovea_case(fov_env, gym, "flex", "flex_resize_rel_aa1", fs=2, mode="relative",
+                             resize_to_full=True, mask_out=False, antialias=True, steps=8, seed=450, **std))
+    # small / non-square geometry, full float64 outputs
+    small = dict(obs=(36, 48), fov=(10, 16), out_dtype=np.float64)
+    paths.append(_fovea_case(fov_env, gym, "fixed", "small_fixed_resize", fs=3, mode="absolute",
+                             resize_to_full=True, mask_out=False, antialias=True, steps=4, seed=500, **small))
+    for aa in (False, True):
+        paths.append(_fovea_case(fov_env, gym, "per", f"small_per_aa{int(aa)}", fs=3, mode="relative",
+                                 resize_to_full=True, mask_out=False, antialias=aa, steps=4, seed=510 + aa,
+                                 per=(9, 7), sas=(-6.0, 6.0), **small))
+        paths.append(_fovea_case(fov_env, gym, "flex", f"small_flex_resize_aa{int(aa)}", fs=3, mode="absolute",
+                                 resize_to_full=True, mask_out=False, antialias=aa, steps=8, seed=520 + aa,
+                                 **small))
+    return paths
+
+
+# ------------------------------------------------------------------ atari control-flow goldens
+def _atari_case(atari_env, name, seed, obs=(16, 16), fs=4, ar=4, clip=False, training=True,
+                steps=260, n_actions=4, fixed_fov=False):
+    ale = ScriptedALE(seed=seed, screen_hw=obs, n_actions=n_actions)
+    _STATE["next_ale"] = ale
+    random.seed(seed)
+    noops = []
+    orig = random.randrange
+
+    def rec_randrange(n):
+        v = orig(n)
+        noops.append(v)
+        return v
+
+    atari_env.random.randrange = rec_randrange
+    try:
+        kw = dict(frame_stack=fs, action_repeat=ar, clip_reward=clip)
+        if fixed_fov:
+            kw.update(fov_size=(6, 6), fov_init_loc=(2, 3), sensory_action_mode="absolute",
+                      resize_to_full=True)
+        args = atari_env.AtariEnvArgs(game="scripted", seed=seed, obs_size=tuple(obs), **kw)
+        env = atari_env.AtariFixedFovealEnv(args) if fixed_fov else atari_env.AtariBaseEnv(args)
+        if not training:
+            env.eval()
+        arng = np.random.default_rng(seed + 1)
+        motor = arng.integers(0, n_actions, size=steps)
+        sens = arng.uniform(-2, 14, size=(steps, 2))
+        states, rewards, dones, ep_len, cum, is_reset, fov_loc = [], [], [], [], [], [], []
+        s, info = env.reset()
+        states.append(s); rewards.append(0.0); dones.append(False)
+        ep_len.append(info["ep_len"]); cum.append(info["reward"]); is_reset.append(True)
+        fov_loc.append(info.get("fov_loc", np.zeros(2)))
+        for t in range(steps):
+            a = int(motor[t])
+            if fixed_fov:
+                s, r, d, tr, info = env.step({"motor_action": a, "sensory_action": sens[t]})
+            else:
+                s, r, d, tr, info = env.step(a)
+            assert tr is False
+            states.append(s); rewards.append(float(r)); dones.append(bool(d))
+            ep_len.append(info["ep_len"]); cum.append(info["reward"]); is_reset.append(False)
+            fov_loc.append(info.get("fov_loc", np.zeros(2)))
+            if d:
+                s, info = env.reset()
+                states.append(s); rewards.append(0.0); dones.append(False)
+                ep_len.append(info["ep_len"]); cum.append(info["reward"]); is_reset.append(True)
+                fov_loc.append(info.get("fov_loc", np.zeros(2)))
+    finally:
+        atari_env.random.randrange = orig
+    states = np.stack(states)
+    assert states.dtype == np.float64
+    rec = dict(seed=seed, obs_size=np.array(obs), frame_stack=fs, action_repeat=ar, clip_reward=clip,
+               training=training, n_actions=n_actions, fixed_fov=fixed_fov, motor=motor, sens=sens,
+               noops=np.array(noops, dtype=np.int64), rewards=np.array(rewards), dones=np.array(dones),
+               ep_len=np.array(ep_len, dtype=np.int64), cum_reward=np.array(cum, dtype=np.float64),
+               is_reset=np.array(is_reset), fov_loc=np.array(fov_loc, dtype=np.int64))
+    if fixed_fov:
+        rec["states_f64"] = states
+    else:
+        u8 = np.rint(states * 255.0).astype(np.uint8)
+        assert np.array_equal((u8.astype(np.float32) / np.float32(255.0)).astype(np.float64), states), \
+            "base-env states must be float32-exact k/255"
+        rec["states_u8"] = u8
+    path = os.path.join(HERE, f"atari_{name}.npz")
+    np.savez_compressed(path, **rec)
+    return path
+
+
+def make_atari(atari_env):
+    return [
+        _atari_case(atari_env, "train_ar4", seed=11),
+        _atari_case(atari_env, "eval_ar4_clip", seed=12, clip=True, training=False),
+        _atari_case(atari_env, "train_ar3_fs3", seed=13, ar=3, fs=3, steps=120),
+        _atari_case(atari_env, "train_ar1", seed=14, ar=1, steps=60),
+        _atari_case(atari_env, "train_ar6_2act", seed=15, ar=6, n_actions=2, steps=160),
+        _atari_case(atari_env, "fixedfov_train_ar4", seed=16, steps=100, fixed_fov=True),
+    ]
+
+
+def main():
+    if not os.path.isdir(REF):
+        raise SystemExit(f"reference checkout not found at {REF}; goldens are generated in the build container only")
+    _install_standins()
+    fov_env, atari_env = _load_reference()
+    gym = sys.modules["gymnasium"]
+    paths = make_fovea(fov_env, gym) + make_atari(atari_env)
+    total = 0
+    for p in paths:
+        sz = os.path.getsize(p)
+        total += sz
+        print(f"{os.path.relpath(p, REPO):60s} {sz/1024:9.1f} KiB")
+    print(f"total {total/1e6:.2f} MB in {len(paths)} files")
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,108 @@
+"""CPU: pin the oracle's NumPy restatement of torchvision Resize arithmetic
+against torch's own CPU kernels (torch.nn.functional.interpolate), and its
+integer stages (ALE luminance, OpenCV 8-bit INTER_LINEAR) with known-answer
+tests.  The integer stages are "parity unpinned" w.r.t. the real cv2 / ALE
+binaries (absent from the image)."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import oracle as O
+
+
+@pytest.mark.parametrize("aa", [False, True])
+@pytest.mark.parametrize("shape,size", [
+    ((4, 30, 30), (84, 84)), ((4, 84, 84), (20, 20)), ((4, 20, 20), (84, 84)),
+    ((2, 50, 40), (30, 30)), ((2, 30, 30), (50, 40)), ((3, 84, 84), (30, 30)),
+    ((1, 7, 84), (30, 30)), ((1, 84, 6), (84, 84)), ((2, 36, 48), (9, 7)), ((2, 9, 7), (36, 48)),
+    ((1, 84, 84), (5, 5)), ((1, 33, 77), (33, 78)),
+])
+def test_resize_matches_torch_float64(shape, size, aa):
+    rng = np.random.default_rng(hash((shape, size, aa)) & 0xFFFF)
+    x = rng.random(shape)
+    want = torch.nn.functional.interpolate(torch.from_numpy(x)[None], size=size, mode="bilinear",
+                                           align_corners=False, antialias=aa)[0].numpy()
+    got = O.resize_bilinear(x, size, aa)
+    np.testing.assert_allclose(got, want, rtol=0, atol=1e-13)   # summation order only
+
+
+def test_aa_equals_plain_when_upscaling():
+    x = np.random.default_rng(3).random((4, 30, 30))
+    np.testing.assert_allclose(O.resize_bilinear(x, (84, 84), True), O.resize_bilinear(x, (84, 84), False),
+                               rtol=0, atol=2e-15)
+
+
+def test_tv_resize_same_size_is_identity():
+    x = np.random.default_rng(4).random((2, 30, 30))
+    assert O.tv_resize(x, (30, 30), True) is not None
+    assert np.array_equal(O.tv_resize(x, (30, 30), True), x)
+
+
+# ---- integer stages: known answers -------------------------------------------------
+
+def test_luminance_known_answers():
+    rgb = np.array([[0, 0, 0], [255, 255, 255], [255, 0, 0], [0, 255, 0], [0, 0, 255], [1, 1, 1],
+                    [200, 72, 72], [45, 50, 184]], dtype=np.uint8)
+    # round(.2989r + .5870g + .1140b): white -> 254.97.. -> 255 ; red 76.2 -> 76 ; green 149.7 -> 150 ; blue 29.07 -> 29
+    want = np.array([0, 255, 76, 150, 29, 1, 110, 64], dtype=np.uint8)
+    assert np.array_equal(O.ale_luminance(rgb), want)
+
+
+def test_cv_resize_constant_and_range():
+    for v in (0, 1, 127, 128, 254, 255):
+        img = np.full((210, 160), v, np.uint8)
+        out = O.cv_resize_linear_u8(img, (84, 84))
+        assert out.shape == (84, 84) and (out == v).all(), v
+
+
+def test_cv_resize_identity_scale():
+    img = np.random.default_rng(0).integers(0, 256, (84, 84), dtype=np.uint8)
+    assert np.array_equal(O.cv_resize_linear_u8(img, (84, 84)), img)
+
+
+def test_cv_resize_exact_2x_is_rounded_mean():
+    # scale 2: f = 2d+0.5 -> both coefficients 1024 -> ((1024*(h>>4))>>16 ...) of 2x2 block sums
+    img = np.random.default_rng(1).integers(0, 256, (40, 60), dtype=np.uint8)
+    out = O.cv_resize_linear_u8(img, (30, 20))
+    s = img.astype(np.int64)
+    h = (s[:, 0::2] + s[:, 1::2]) * 1024
+    top, bot = h[0::2], h[1::2]
+    want = (((1024 * (top >> 4)) >> 16) + ((1024 * (bot >> 4)) >> 16) + 2) >> 2
+    assert np.array_equal(out, want.astype(np.uint8))
+
+
+def test_cv_tables_atari_geometry():
+    x0, x1, a0, a1 = O.cv_tables_x(160, 84)
+    y0, y1, b0, b1 = O.cv_tables_y(210, 84)
+    assert (a0 + a1 == 2048).all() and (b0 + b1 == 2048).all()
+    assert (x1 == x0 + 1).all() and (y1 == y0 + 1).all()
+    assert y0[:4].tolist() == [0, 3, 5, 8] and b1[:2].tolist() == [1536, 512]   # f = .75, .25
+    assert x0[0] == 0 and x0[-1] == 158 and y0[-1] == 208
+    rows = np.unique(np.concatenate([y0, y1]))
+    assert rows.size == 168                                                      # 168 of 210 rows touched
+
+
+def test_cv_resize_ramp_monotone_and_upscale_clamps():
+    ramp = np.tile(np.arange(160, dtype=np.uint8), (210, 1))
+    out = O.cv_resize_linear_u8(ramp, (84, 84))
+    assert (np.diff(out.astype(int), axis=1) >= 0).all() and (out == out[0]).all()
+    small = np.random.default_rng(2).integers(0, 256, (5, 7), dtype=np.uint8)
+    up = O.cv_resize_linear_u8(small, (21, 15))
+    assert up.shape == (15, 21)
+    assert up[0, 0] == small[0, 0] and up[-1, -1] == small[-1, -1]               # clamped borders copy the corner
+
+
+def test_ring_oracle_semantics():
+    rng = np.random.default_rng(5)
+    ring = O.RingOracle(3, frame_stack=3, obs_size=(84, 84))
+    frames = rng.integers(0, 256, (3, 2, 210, 160, 3), dtype=np.uint8)
+    ring.ingest(frames, nvalid=[2, 1, 0])
+    st = ring.stack_u8()
+    f0 = O.get_state_u8(frames[0, 0], (84, 84))
+    f1 = O.get_state_u8(frames[0, 1], (84, 84))
+    assert np.array_equal(st[0, -1], np.maximum(f0, f1)) and (st[0, :-1] == 0).all()
+    assert np.array_equal(st[1, -1], O.get_state_u8(frames[1, 0], (84, 84)))
+    assert (st[2] == 0).all()
+    ring.ingest(frames[::-1].copy(), nvalid=[1, 1, 1], clear=[0, 1, 0], skip=[0, 0, 1])
+    st2 = ring.stack_u8()
+    assert np.array_equal(st2[0, 1], st[0, 2]) and (st2[1, :2] == 0).all() and np.array_equal(st2[2], st[2])
