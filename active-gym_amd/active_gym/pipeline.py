@@ -1,0 +1,213 @@
+"""ObsPipeline — the batched, device-resident observation pipeline of N
+environments on one MI355X.  PyTorch tensors are only the device-buffer / FFI
+surface: every operation is one launch of a hand-written HIP kernel in
+libagx.so through the C ABI (include/agx.h).
+
+It replaces, for N envs at once, what the reference does per env on the CPU:
+``AtariEnv._get_state/_step/_reset`` image work (reference atari_env.py:73-148)
+and ``*FovealEnv._fov_step/_get_fov_state`` (reference fov_env.py:166-203,270-330,
+375-388).
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Optional, Sequence, Tuple
+
+import numpy as np
+import torch
+
+from . import _native as nat
+
+_KINDS = {"base": nat.KIND_BASE, "fixed": nat.KIND_FIXED, "flexible": nat.KIND_FLEXIBLE,
+          "peripheral": nat.KIND_PERIPHERAL}
+_DT = {torch.float32: nat.DT_F32, torch.float64: nat.DT_F64, torch.int32: nat.DT_I32, torch.int64: nat.DT_I64}
+
+
+def resolve_out_mode(mask_out: bool, resize_to_full: bool) -> int:
+    """Priority of reference fov_env.py:176-185: mask_out > resize_to_full > raw."""
+    if mask_out:
+        return nat.OUT_MASK
+    if resize_to_full:
+        return nat.OUT_RESIZE
+    return nat.OUT_RAW
+
+
+class ObsPipeline:
+    def __init__(self, num_envs: int, kind: str = "fixed", obs_size: Tuple[int, int] = (84, 84),
+                 frame_stack: int = 4, fov_size: Optional[Tuple[int, int]] = None,
+                 fov_init_loc: Sequence[float] = (0, 0), sensory_action_mode: str = "absolute",
+                 sensory_action_space: Optional[Sequence[float]] = None, resize_to_full: bool = False,
+                 mask_out: bool = False, peripheral_res: Optional[Tuple[int, int]] = None,
+                 antialias: bool = True, device: Optional[torch.device] = None):
+        if not torch.cuda.is_available():
+            raise RuntimeError("ObsPipeline needs a ROCm GPU: the observation path has no CPU implementation")
+        self._lib = nat.lib()
+        self.device = torch.device(device if device is not None else f"cuda:{torch.cuda.current_device()}")
+        if self.device.type != "cuda":
+            raise ValueError(f"device must be a cuda (ROCm) device, got {self.device}")
+        if self.device.index is None:
+            self.device = torch.device("cuda", torch.cuda.current_device())
+        if kind not in _KINDS:
+            raise ValueError(f"kind must be one of {sorted(_KINDS)}")
+        if sensory_action_mode not in ("absolute", "relative"):
+            raise ValueError("sensory_action_mode must be 'absolute' or 'relative'")
+        self.kind = kind
+        self.num_envs = int(num_envs)
+        self.obs_size = (int(obs_size[0]), int(obs_size[1]))
+        self.frame_stack = int(frame_stack)
+        cfg = nat.AgxConfig()
+        cfg.struct_size = C.sizeof(nat.AgxConfig)
+        cfg.device = self.device.index
+        cfg.num_envs = self.num_envs
+        cfg.kind = _KINDS[kind]
+        cfg.raw_h, cfg.raw_w = nat.RAW_H, nat.RAW_W
+        cfg.obs_h, cfg.obs_w = self.obs_size
+        cfg.frame_stack = self.frame_stack
+        if kind != "base":
+            if fov_size is None:
+                raise ValueError("fov_size is required")
+            fov = np.asarray(fov_size)
+            # reference fov_env.py:112
+            if not (fov < np.asarray(self.obs_size)).all():
+                raise ValueError(f"fov_size {tuple(fov_size)} must be smaller than obs_size {self.obs_size}")
+            cfg.fov_h, cfg.fov_w = int(fov_size[0]), int(fov_size[1])
+            cfg.init_loc[0], cfg.init_loc[1] = float(fov_init_loc[0]), float(fov_init_loc[1])
+            cfg.action_mode = nat.MODE_RELATIVE if sensory_action_mode == "relative" else nat.MODE_ABSOLUTE
+            if sensory_action_mode == "relative":
+                if sensory_action_space is None:
+                    raise ValueError("relative mode needs sensory_action_space=(lo, hi)")
+                cfg.sas_lo, cfg.sas_hi = float(sensory_action_space[0]), float(sensory_action_space[1])
+            if kind == "peripheral":
+                if peripheral_res is None:
+                    raise ValueError("peripheral_res is required")
+                cfg.per_h, cfg.per_w = int(peripheral_res[0]), int(peripheral_res[1])
+                cfg.out_mode = nat.OUT_RESIZE          # fov_env.py:361-364: mask_out forced off, full-size obs
+            else:
+                cfg.out_mode = resolve_out_mode(mask_out, resize_to_full)
+            cfg.antialias = 1 if antialias else 0
+        self.fov_size = (cfg.fov_h, cfg.fov_w)
+        self.out_mode = cfg.out_mode
+        self._cfg = cfg
+        self._ctx = C.c_void_p()
+        nat.check(self._lib.agx_create(C.byref(cfg), C.byref(self._ctx)))
+        dims = (C.c_int32 * 4)()
+        nat.check(self._lib.agx_obs_shape(self._ctx, C.byref(dims)), self._ctx)
+        self.obs_shape = tuple(int(d) for d in dims)
+        self.full_shape = (self.num_envs, self.frame_stack) + self.obs_size
+
+    # ------------------------------------------------------------------ plumbing
+    def close(self):
+        if getattr(self, "_ctx", None) is not None and self._ctx.value:
+            self._lib.agx_destroy(self._ctx)
+            self._ctx = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _stream(self):
+        return C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
+
+    def _chk(self, t: torch.Tensor, shape, dtype, name):
+        if not isinstance(t, torch.Tensor):
+            raise TypeError(f"{name} must be a torch.Tensor")
+        if t.device != self.device:
+            raise ValueError(f"{name} is on {t.device}, pipeline is on {self.device}")
+        if dtype is not None and t.dtype != dtype:
+            raise TypeError(f"{name} must be {dtype}, got {t.dtype}")
+        if tuple(t.shape) != tuple(shape):
+            raise ValueError(f"{name} must have shape {tuple(shape)}, got {tuple(t.shape)}")
+        if not t.is_contiguous():
+            raise ValueError(f"{name} must be contiguous")
+        return C.c_void_p(t.data_ptr())
+
+    def algorithmic_bytes(self, kernel: str) -> int:
+        k = {"ingest": nat.K_INGEST, "fovea": nat.K_FOVEA, "full": nat.K_FULL}[kernel]
+        v = self._lib.agx_algorithmic_bytes(self._ctx, k)
+        if v < 0:
+            raise nat.AgxError(int(v), "algorithmic_bytes")
+        return int(v)
+
+    # ------------------------------------------------------------------ K1
+    def ingest(self, frames: torch.Tensor, cmd: torch.Tensor):
+        """frames u8[N,2,210,160,3] RGB, cmd u8[N] (nvalid | CMD_CLEAR | CMD_SKIP)."""
+        pf = self._chk(frames, (self.num_envs, 2, nat.RAW_H, nat.RAW_W, 3), torch.uint8, "frames")
+        pc = self._chk(cmd, (self.num_envs,), torch.uint8, "cmd")
+        nat.check(self._lib.agx_ingest(self._ctx, pf, pc, self._stream()), self._ctx)
+
+    def ingest_gray(self, small: torch.Tensor, cmd: torch.Tensor):
+        """small u8[N,2,obs_h,obs_w] already obs-sized gray frames."""
+        ps = self._chk(small, (self.num_envs, 2) + self.obs_size, torch.uint8, "small")
+        pc = self._chk(cmd, (self.num_envs,), torch.uint8, "cmd")
+        nat.check(self._lib.agx_ingest_gray(self._ctx, ps, pc, self._stream()), self._ctx)
+
+    # ------------------------------------------------------------------ K0
+    def observe_full(self, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+        if out is None:
+            out = torch.empty(self.full_shape, dtype=torch.float32, device=self.device)
+        po = self._chk(out, self.full_shape, torch.float32, "out")
+        nat.check(self._lib.agx_observe_full(self._ctx, po, self._stream()), self._ctx)
+        return out
+
+    def stack_u8(self) -> torch.Tensor:
+        out = torch.empty(self.full_shape, dtype=torch.uint8, device=self.device)
+        nat.check(self._lib.agx_get_stack_u8(self._ctx, C.c_void_p(out.data_ptr()), self._stream()), self._ctx)
+        return out
+
+    def set_stack_u8(self, stack: torch.Tensor):
+        ps = self._chk(stack, self.full_shape, torch.uint8, "stack")
+        nat.check(self._lib.agx_set_stack_u8(self._ctx, ps, self._stream()), self._ctx)
+
+    # ------------------------------------------------------------------ fovea
+    def fovea_reset(self, mask: Optional[torch.Tensor] = None):
+        pm = self._chk(mask, (self.num_envs,), torch.uint8, "mask") if mask is not None else None
+        nat.check(self._lib.agx_fovea_reset(self._ctx, pm, self._stream()), self._ctx)
+
+    def fov_state(self):
+        loc = torch.empty((self.num_envs, 2), dtype=torch.int32, device=self.device)
+        res = torch.empty((self.num_envs, 2), dtype=torch.int32, device=self.device)
+        nat.check(self._lib.agx_get_fov_state(self._ctx, C.c_void_p(loc.data_ptr()), C.c_void_p(res.data_ptr()),
+                                              self._stream()), self._ctx)
+        return loc, res
+
+    def set_fov_state(self, loc: Optional[torch.Tensor] = None, res: Optional[torch.Tensor] = None):
+        pl = self._chk(loc, (self.num_envs, 2), torch.int32, "loc") if loc is not None else None
+        pr = self._chk(res, (self.num_envs, 2), torch.int32, "res") if res is not None else None
+        nat.check(self._lib.agx_set_fov_state(self._ctx, pl, pr, self._stream()), self._ctx)
+
+    def fovea(self, action: Optional[torch.Tensor] = None, action_type: Optional[torch.Tensor] = None,
+              mask: Optional[torch.Tensor] = None, out: Optional[torch.Tensor] = None,
+              loc_out: Optional[torch.Tensor] = None, res_out: Optional[torch.Tensor] = None):
+        """One ``_fov_step`` for all envs.  action [N,2] (f32/f64/i32/i64) or None
+        (observe at the current fov_loc).  Returns (obs, fov_loc[, fov_res])."""
+        if self.kind == "base":
+            raise RuntimeError("base pipeline has no fovea; use observe_full()")
+        N = self.num_envs
+        pa, dt = None, 0
+        if action is not None:
+            if action.dtype not in _DT:
+                raise TypeError(f"sensory action dtype {action.dtype} not supported (f32/f64/i32/i64)")
+            pa = self._chk(action, (N, 2), None, "action")
+            dt = _DT[action.dtype]
+        pm = self._chk(mask, (N,), torch.uint8, "mask") if mask is not None else None
+        if out is None:
+            out = torch.empty(self.obs_shape, dtype=torch.float32, device=self.device)
+        po = self._chk(out, self.obs_shape, torch.float32, "out")
+        if loc_out is None:
+            loc_out = torch.empty((N, 2), dtype=torch.int32, device=self.device)
+        pl = self._chk(loc_out, (N, 2), torch.int32, "loc_out")
+        st = self._stream()
+        if self.kind == "fixed":
+            nat.check(self._lib.agx_fovea_fixed(self._ctx, pa, dt, pm, po, pl, st), self._ctx)
+            return out, loc_out
+        if self.kind == "peripheral":
+            nat.check(self._lib.agx_fovea_peripheral(self._ctx, pa, dt, pm, po, pl, st), self._ctx)
+            return out, loc_out
+        pt = self._chk(action_type, (N,), torch.int32, "action_type") if action_type is not None else None
+        if res_out is None:
+            res_out = torch.empty((N, 2), dtype=torch.int32, device=self.device)
+        pr = self._chk(res_out, (N, 2), torch.int32, "res_out")
+        nat.check(self._lib.agx_fovea_flexible(self._ctx, pa, dt, pt, pm, po, pl, pr, st), self._ctx)
+        return out, loc_out, res_out

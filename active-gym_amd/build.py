@@ -1,0 +1,51 @@
+#!/usr/bin/env python3
+"""Build libagx.so (the HIP extension behind include/agx.h) for gfx950, in-tree.
+
+    python active-gym_amd/build.py            # -> active-gym_amd/lib/libagx.so
+
+hipcc cross-compiles without a GPU; the .so is git-ignored but travels with
+gpurun snapshots.
+"""
+import os
+import shutil
+import subprocess
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+REPO = os.path.dirname(HERE)
+SRC = os.path.join(HERE, "csrc", "agx_api.hip")
+DEPS = [SRC] + [os.path.join(HERE, "csrc", f) for f in ("agx_kernels.h", "agx_taps.h")] + \
+       [os.path.join(REPO, "include", "agx.h")]
+OUT_DIR = os.path.join(HERE, "lib")
+OUT = os.path.join(OUT_DIR, "libagx.so")
+
+
+def hipcc():
+    for cand in (os.environ.get("HIPCC"), shutil.which("hipcc"), "/opt/rocm/bin/hipcc"):
+        if cand and os.path.exists(cand):
+            return cand
+    raise RuntimeError("hipcc not found (set HIPCC=...)")
+
+
+def up_to_date():
+    return os.path.exists(OUT) and all(os.path.getmtime(OUT) >= os.path.getmtime(d) for d in DEPS)
+
+
+def build(force=False, verbose=False, extra=()):
+    if not force and up_to_date():
+        return OUT
+    os.makedirs(OUT_DIR, exist_ok=True)
+    cmd = [hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared",
+           "-fvisibility=hidden", "-Wall", "-Wno-unused-function",
+           "-I", os.path.join(REPO, "include"), "-I", os.path.join(HERE, "csrc"),
+           "-DAGX_BUILD", *extra, SRC, "-o", OUT + ".tmp"]
+    if verbose:
+        print(" ".join(cmd))
+    subprocess.run(cmd, check=True)
+    os.replace(OUT + ".tmp", OUT)
+    return OUT
+
+
+if __name__ == "__main__":
+    extra = [a for a in sys.argv[1:] if a.startswith("-") and a not in ("-f", "-v")]
+    print(build(force="-f" in sys.argv, verbose=True, extra=extra))

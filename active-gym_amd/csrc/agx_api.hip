@@ -1,0 +1,540 @@
+// agx_api.hip — the C ABI declared in include/agx.h: context, table builders, launches.
+// Built for gfx950 only (see ../build.py): hipcc --offload-arch=gfx950 -shared -fPIC.
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <new>
+#include <set>
+#include <string>
+#include <vector>
+
+#include "agx.h"
+#include "agx_kernels.h"
+
+using namespace agx;
+
+struct agx_ctx {
+    agx_config cfg;
+    uint8_t *ring = nullptr;
+    int32_t *head[2] = {nullptr, nullptr};
+    int32_t *loc[2] = {nullptr, nullptr};
+    int32_t *res[2] = {nullptr, nullptr};
+    int cur_head = 0;
+    int cur_fov = 0;
+    int2 *in_xtab = nullptr;   // K1 tables
+    int4 *in_ytab = nullptr;
+    Tap *fx_xtab = nullptr;    // K2 tables
+    Tap *fx_ytab = nullptr;
+    int band_rows = 0;
+    int rows_touched = 0;
+    int init_r = 0, init_c = 0;
+    std::string err;
+};
+
+namespace {
+
+thread_local std::string g_create_err;
+
+int fail(agx_ctx *ctx, int code, const char *fmt, ...) {
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    if (ctx)
+        ctx->err = buf;
+    else
+        g_create_err = buf;
+    return code;
+}
+
+#define AGX_HIP(ctx, expr)                                                                     \
+    do {                                                                                       \
+        hipError_t e_ = (expr);                                                                \
+        if (e_ != hipSuccess) return fail((ctx), AGX_E_HIP, "%s: %s", #expr, hipGetErrorString(e_)); \
+    } while (0)
+
+struct DeviceGuard {
+    int prev = -1;
+    bool ok = true;
+    explicit DeviceGuard(int dev) {
+        if (hipGetDevice(&prev) != hipSuccess) prev = -1;
+        if (prev != dev) ok = hipSetDevice(dev) == hipSuccess;
+    }
+    ~DeviceGuard() {
+        if (prev >= 0) (void)hipSetDevice(prev);
+    }
+};
+
+inline hipStream_t S(void *s) { return static_cast<hipStream_t>(s); }
+
+// ---- OpenCV 8-bit INTER_LINEAR tables (imgproc/src/resize.cpp), see oracle/oracle.py for the
+// restated algorithm: inv_scale = dst/src, scale = 1/inv_scale, f = (float)((d+.5)*scale-.5),
+// s = floor(f), f -= s, coefficients = rint-half-even(float * 2048).
+inline int cv_round_f(float v) { return (int)std::nearbyintf(v); }   // default mode: half-to-even
+
+void cv_axis(int src, int dst, bool is_x, std::vector<int> &i0, std::vector<int> &i1,
+             std::vector<int> &c0, std::vector<int> &c1) {
+    const double inv_scale = (double)dst / (double)src;
+    const double scale = 1.0 / inv_scale;
+    i0.resize(dst); i1.resize(dst); c0.resize(dst); c1.resize(dst);
+    for (int d = 0; d < dst; ++d) {
+        float f = (float)((d + 0.5) * scale - 0.5);
+        int s = (int)std::floor(f);
+        f -= (float)s;
+        if (is_x) {                       // x axis: clamp index and zero the fraction
+            if (s < 0) { s = 0; f = 0.f; }
+            if (s >= src - 1) { s = src - 1; f = 0.f; }
+            i0[d] = s;
+            i1[d] = std::min(s + 1, src - 1);
+        } else {                          // y axis: keep coefficients, clip the row indices
+            i0[d] = std::min(std::max(s, 0), src - 1);
+            i1[d] = std::min(std::max(s + 1, 0), src - 1);
+        }
+        c0[d] = cv_round_f((1.f - f) * 2048.f);
+        c1[d] = cv_round_f(f * 2048.f);
+    }
+}
+
+template <class T>
+int upload(agx_ctx *ctx, T **dptr, const std::vector<T> &h) {
+    AGX_HIP(ctx, hipMalloc(reinterpret_cast<void **>(dptr), h.size() * sizeof(T)));
+    AGX_HIP(ctx, hipMemcpy(*dptr, h.data(), h.size() * sizeof(T), hipMemcpyHostToDevice));
+    return AGX_OK;
+}
+
+bool has_fovea(const agx_config &c) { return c.kind != AGX_KIND_BASE; }
+
+size_t fixed_lds(const agx_config &c) {
+    const size_t s = ((size_t)c.fov_h * c.fov_w + 3) & ~(size_t)3;
+    return (s + (c.out_mode == AGX_OUT_RESIZE ? (size_t)c.fov_h * c.obs_w : 0)) * sizeof(float);
+}
+
+// second LDS buffer of the generic kernels, in floats: flexible ping-pongs two full frames,
+// peripheral keeps A[oh][pw] | B[ph][pw] | C[ph][ow] there
+size_t generic_buf1(const agx_config &c) {
+    const size_t cap = ((size_t)c.obs_h * c.obs_w + 3) & ~(size_t)3;
+    if (c.kind != AGX_KIND_PERIPHERAL) return cap;
+    const size_t abc = (size_t)c.obs_h * c.per_w + (size_t)c.per_h * c.per_w + (size_t)c.per_h * c.obs_w;
+    return (abc + 3) & ~(size_t)3;
+}
+
+size_t generic_lds(const agx_config &c) {
+    const size_t cap = ((size_t)c.obs_h * c.obs_w + 3) & ~(size_t)3;
+    int tmax = std::max(std::max(c.obs_h, c.obs_w), std::max(c.fov_h, c.fov_w));
+    if (c.kind == AGX_KIND_PERIPHERAL) tmax = std::max(tmax, std::max(c.per_h, c.per_w));
+    return (cap + generic_buf1(c)) * sizeof(float) + (size_t)tmax * sizeof(Tap);
+}
+
+constexpr size_t kMaxLds = 64 * 1024;
+
+}  // namespace
+
+extern "C" {
+
+int agx_abi_version(void) { return AGX_ABI_VERSION; }
+
+const char *agx_last_error(const agx_ctx *ctx) { return ctx ? ctx->err.c_str() : g_create_err.c_str(); }
+
+int agx_destroy(agx_ctx *ctx) {
+    if (!ctx) return AGX_OK;
+    DeviceGuard g(ctx->cfg.device);
+    void *ptrs[] = {ctx->ring, ctx->head[0], ctx->head[1], ctx->loc[0], ctx->loc[1], ctx->res[0], ctx->res[1],
+                    ctx->in_xtab, ctx->in_ytab, ctx->fx_xtab, ctx->fx_ytab};
+    for (void *p : ptrs)
+        if (p) (void)hipFree(p);
+    delete ctx;
+    return AGX_OK;
+}
+
+int agx_create(const agx_config *cfg, agx_ctx **out) {
+    if (!cfg || !out) return fail(nullptr, AGX_E_INVALID, "agx_create: null argument");
+    *out = nullptr;
+    if (cfg->struct_size != (int32_t)sizeof(agx_config))
+        return fail(nullptr, AGX_E_INVALID, "agx_create: struct_size %d != %zu (ABI mismatch)", cfg->struct_size,
+                    sizeof(agx_config));
+    const agx_config &c = *cfg;
+    if (c.num_envs < 1 || c.num_envs > 65535)   // env index rides on gridDim.y / gridDim.z
+        return fail(nullptr, AGX_E_INVALID, "num_envs must be in [1, 65535] per context (shard larger batches)");
+    if (c.raw_h != kRawH || c.raw_w != kRawW)
+        return fail(nullptr, AGX_E_INVALID, "raw screen must be %dx%d (ALE), got %dx%d", kRawH, kRawW, c.raw_h, c.raw_w);
+    if (c.obs_h < 4 || c.obs_w < 4 || (c.obs_w & 3) || c.obs_w > 1024 || c.obs_h > 1024)
+        return fail(nullptr, AGX_E_INVALID, "obs_size (%d,%d): need 4 <= h,w <= 1024 and w %% 4 == 0", c.obs_h, c.obs_w);
+    if (c.frame_stack < 1 || c.frame_stack > 16) return fail(nullptr, AGX_E_INVALID, "frame_stack must be in [1,16]");
+    if (c.kind < AGX_KIND_BASE || c.kind > AGX_KIND_PERIPHERAL) return fail(nullptr, AGX_E_INVALID, "unknown kind %d", c.kind);
+    if (has_fovea(c)) {
+        // assert (np.array(self.fov_size) < np.array(self.obs_size)).all()   fov_env.py:112
+        if (c.fov_h < 1 || c.fov_w < 1 || c.fov_h >= c.obs_h || c.fov_w >= c.obs_w)
+            return fail(nullptr, AGX_E_INVALID, "fov_size (%d,%d) must be >= 1 and < obs_size (%d,%d)", c.fov_h, c.fov_w,
+                        c.obs_h, c.obs_w);
+        if (c.out_mode < AGX_OUT_RAW || c.out_mode > AGX_OUT_MASK) return fail(nullptr, AGX_E_INVALID, "bad out_mode");
+        if (c.action_mode != AGX_MODE_ABSOLUTE && c.action_mode != AGX_MODE_RELATIVE)
+            return fail(nullptr, AGX_E_INVALID, "bad action_mode");
+        if (c.action_mode == AGX_MODE_RELATIVE && !(c.sas_lo <= c.sas_hi))
+            return fail(nullptr, AGX_E_INVALID, "relative mode needs sensory_action_space lo <= hi");
+        if (!std::isfinite(c.init_loc[0]) || !std::isfinite(c.init_loc[1]))
+            return fail(nullptr, AGX_E_INVALID, "fov_init_loc must be finite");
+        if (c.kind == AGX_KIND_PERIPHERAL && (c.per_h < 1 || c.per_w < 1 || c.per_h > 1024 || c.per_w > 1024))
+            return fail(nullptr, AGX_E_INVALID, "peripheral_res (%d,%d) out of range", c.per_h, c.per_w);
+        const size_t lds = c.kind == AGX_KIND_FIXED ? fixed_lds(c) : generic_lds(c);
+        if (lds > kMaxLds)
+            return fail(nullptr, AGX_E_INVALID, "geometry needs %zu B of LDS per workgroup (limit %zu)", lds, kMaxLds);
+    }
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1)
+        return fail(nullptr, AGX_E_HIP, "no HIP device: libagx has no CPU path");
+    if (c.device < 0 || c.device >= ndev) return fail(nullptr, AGX_E_INVALID, "device %d out of range (%d visible)", c.device, ndev);
+
+    agx_ctx *ctx = new (std::nothrow) agx_ctx;
+    if (!ctx) return fail(nullptr, AGX_E_NOMEM, "out of host memory");
+    ctx->cfg = c;
+    DeviceGuard g(c.device);
+    int rc = AGX_OK;
+    auto bail = [&](int code) {
+        g_create_err = ctx->err;
+        agx_destroy(ctx);
+        return code;
+    };
+    const size_t N = c.num_envs, fsz = (size_t)c.obs_h * c.obs_w;
+#define TRY(expr)                                  \
+    do {                                           \
+        hipError_t e_ = (expr);                    \
+        if (e_ != hipSuccess) {                    \
+            fail(ctx, AGX_E_HIP, "%s: %s", #expr, hipGetErrorString(e_)); \
+            return bail(AGX_E_HIP);                \
+        }                                          \
+    } while (0)
+    TRY(hipMalloc(reinterpret_cast<void **>(&ctx->ring), N * c.frame_stack * fsz));
+    TRY(hipMemset(ctx->ring, 0, N * c.frame_stack * fsz));
+    for (int b = 0; b < 2; ++b) {
+        TRY(hipMalloc(reinterpret_cast<void **>(&ctx->head[b]), N * sizeof(int32_t)));
+        TRY(hipMemset(ctx->head[b], 0, N * sizeof(int32_t)));
+    }
+    // K1 tables (only meaningful for square obs; built anyway, agx_ingest checks)
+    {
+        std::vector<int> x0, x1, a0, a1, y0, y1, b0, b1;
+        cv_axis(kRawW, c.obs_w, true, x0, x1, a0, a1);
+        cv_axis(kRawH, c.obs_h, false, y0, y1, b0, b1);
+        std::vector<int2> xt(c.obs_w);
+        std::vector<int4> yt(c.obs_h);
+        for (int i = 0; i < c.obs_w; ++i) xt[i] = make_int2(x0[i] | (x1[i] << 16), (a0[i] & 0xFFFF) | (a1[i] << 16));
+        std::set<int> touched;
+        for (int i = 0; i < c.obs_h; ++i) {
+            yt[i] = make_int4(y0[i], y1[i], b0[i], b1[i]);
+            touched.insert(y0[i]);
+            touched.insert(y1[i]);
+        }
+        ctx->rows_touched = (int)touched.size();
+        if ((rc = upload(ctx, &ctx->in_xtab, xt)) != AGX_OK) return bail(rc);
+        if ((rc = upload(ctx, &ctx->in_ytab, yt)) != AGX_OK) return bail(rc);
+        const int ow4 = c.obs_w / 4;
+        ctx->band_rows = std::max(1, std::min(12, kThreads / ow4));
+    }
+    if (has_fovea(c)) {
+        // _init_fov_loc: np.rint(fov_init_loc).astype(np.int32)  (not clipped)   fov_env.py:149-150
+        ctx->init_r = (int)std::nearbyint(c.init_loc[0]);
+        ctx->init_c = (int)std::nearbyint(c.init_loc[1]);
+        if (ctx->init_r < 0 || ctx->init_c < 0 || ctx->init_r > c.obs_h - c.fov_h || ctx->init_c > c.obs_w - c.fov_w) {
+            fail(ctx, AGX_E_INVALID, "fov_init_loc (%g,%g) puts the %dx%d window outside the %dx%d frame", c.init_loc[0],
+                 c.init_loc[1], c.fov_h, c.fov_w, c.obs_h, c.obs_w);
+            return bail(AGX_E_INVALID);
+        }
+        std::vector<int32_t> loc(2 * N), res(2 * N);
+        for (size_t i = 0; i < N; ++i) {
+            loc[2 * i] = ctx->init_r;
+            loc[2 * i + 1] = ctx->init_c;
+            res[2 * i] = c.fov_h;
+            res[2 * i + 1] = c.fov_w;
+        }
+        for (int b = 0; b < 2; ++b) {
+            if ((rc = upload(ctx, &ctx->loc[b], loc)) != AGX_OK) return bail(rc);
+            if ((rc = upload(ctx, &ctx->res[b], res)) != AGX_OK) return bail(rc);
+        }
+        if (c.kind == AGX_KIND_FIXED && c.out_mode == AGX_OUT_RESIZE) {
+            std::vector<Tap> xt(c.obs_w), yt(c.obs_h);
+            for (int i = 0; i < c.obs_w; ++i) xt[i] = make_tap_lin2(i, c.fov_w, c.obs_w);
+            for (int i = 0; i < c.obs_h; ++i) yt[i] = make_tap_lin2(i, c.fov_h, c.obs_h);
+            if ((rc = upload(ctx, &ctx->fx_xtab, xt)) != AGX_OK) return bail(rc);
+            if ((rc = upload(ctx, &ctx->fx_ytab, yt)) != AGX_OK) return bail(rc);
+        }
+    }
+#undef TRY
+    *out = ctx;
+    return AGX_OK;
+}
+
+int agx_obs_shape(const agx_ctx *ctx, int32_t dims[4]) {
+    if (!ctx || !dims) return AGX_E_INVALID;
+    const agx_config &c = ctx->cfg;
+    dims[0] = c.num_envs;
+    dims[1] = c.frame_stack;
+    const bool crop = c.kind == AGX_KIND_FIXED && c.out_mode == AGX_OUT_RAW;
+    dims[2] = crop ? c.fov_h : c.obs_h;
+    dims[3] = crop ? c.fov_w : c.obs_w;
+    return AGX_OK;
+}
+
+int64_t agx_algorithmic_bytes(const agx_ctx *ctx, int kernel_id) {
+    if (!ctx) return AGX_E_INVALID;
+    const agx_config &c = ctx->cfg;
+    const int64_t N = c.num_envs, fs = c.frame_stack, px = (int64_t)c.obs_h * c.obs_w;
+    switch (kernel_id) {
+        case AGX_K_INGEST:   // two frames, only the source rows the vertical resize touches + one u8 slot
+            return N * (2 * (int64_t)ctx->rows_touched * kRawRowBytes + px);
+        case AGX_K_FULL:
+            return N * fs * px * 5;
+        case AGX_K_FOVEA: {
+            if (!has_fovea(c)) return AGX_E_STATE;
+            const int64_t win = (int64_t)c.fov_h * c.fov_w;
+            if (c.kind == AGX_KIND_PERIPHERAL) return N * fs * px * 5;
+            if (c.kind == AGX_KIND_FIXED && c.out_mode == AGX_OUT_RAW) return N * fs * win * 5;
+            return N * fs * (win + px * 4);
+        }
+        default:
+            return AGX_E_INVALID;
+    }
+}
+
+// ---------------------------------------------------------------- K1
+int agx_ingest(agx_ctx *ctx, const uint8_t *d_frames, const uint8_t *d_cmd, void *stream) {
+    if (!ctx) return AGX_E_INVALID;
+    if (!d_frames || !d_cmd) return fail(ctx, AGX_E_INVALID, "agx_ingest: null buffer");
+    const agx_config &c = ctx->cfg;
+    if (c.obs_h != c.obs_w)
+        return fail(ctx, AGX_E_INVALID,
+                    "agx_ingest: obs_size (%d,%d) is not square; the reference hands obs_size to cv2.resize as "
+                    "(width,height) and fails on non-square sizes (atari_env.py:74,126)", c.obs_h, c.obs_w);
+    DeviceGuard g(c.device);
+    IngestParams p;
+    p.frames = d_frames;
+    p.cmd = d_cmd;
+    p.ring = ctx->ring;
+    p.head_in = ctx->head[ctx->cur_head];
+    p.head_out = ctx->head[ctx->cur_head ^ 1];
+    p.xtab = ctx->in_xtab;
+    p.ytab = ctx->in_ytab;
+    p.oh = c.obs_h;
+    p.ow = c.obs_w;
+    p.fs = c.frame_stack;
+    p.band_rows = ctx->band_rows;
+    const int bands = (c.obs_h + ctx->band_rows - 1) / ctx->band_rows;
+    const size_t lds = sizeof(int4) * ctx->band_rows + (size_t)2 * ctx->band_rows * 2 * kRawW;
+    hipLaunchKernelGGL(k_ingest, dim3(bands, c.num_envs), dim3(kThreads), lds, S(stream), p);
+    AGX_HIP(ctx, hipGetLastError());
+    ctx->cur_head ^= 1;
+    return AGX_OK;
+}
+
+int agx_ingest_gray(agx_ctx *ctx, const uint8_t *d_small, const uint8_t *d_cmd, void *stream) {
+    if (!ctx) return AGX_E_INVALID;
+    if (!d_small || !d_cmd) return fail(ctx, AGX_E_INVALID, "agx_ingest_gray: null buffer");
+    const agx_config &c = ctx->cfg;
+    DeviceGuard g(c.device);
+    IngestGrayParams p;
+    p.small = d_small;
+    p.cmd = d_cmd;
+    p.ring = ctx->ring;
+    p.head_in = ctx->head[ctx->cur_head];
+    p.head_out = ctx->head[ctx->cur_head ^ 1];
+    p.oh = c.obs_h;
+    p.ow = c.obs_w;
+    p.fs = c.frame_stack;
+    const int words = c.obs_h * c.obs_w / 4;
+    hipLaunchKernelGGL(k_ingest_gray, dim3((words + kThreads - 1) / kThreads, c.num_envs), dim3(kThreads), 0,
+                       S(stream), p);
+    AGX_HIP(ctx, hipGetLastError());
+    ctx->cur_head ^= 1;
+    return AGX_OK;
+}
+
+// ---------------------------------------------------------------- K0
+static int stack_launch(agx_ctx *ctx, int which, const uint8_t *in_u8, uint8_t *out_u8, float *out_f32, void *stream) {
+    const agx_config &c = ctx->cfg;
+    DeviceGuard g(c.device);
+    StackParams p;
+    p.ring = ctx->ring;
+    p.head = ctx->head[ctx->cur_head];
+    p.in_u8 = in_u8;
+    p.out_u8 = out_u8;
+    p.out_f32 = out_f32;
+    p.words = c.obs_h * c.obs_w / 4;
+    p.fs = c.frame_stack;
+    const dim3 grid((p.words + kThreads - 1) / kThreads, c.frame_stack, c.num_envs);
+    if (which == 0)
+        hipLaunchKernelGGL(k_stack_u8, grid, dim3(kThreads), 0, S(stream), p);
+    else if (which == 1)
+        hipLaunchKernelGGL(k_set_stack, grid, dim3(kThreads), 0, S(stream), p);
+    else
+        hipLaunchKernelGGL(k_full, grid, dim3(kThreads), 0, S(stream), p);
+    AGX_HIP(ctx, hipGetLastError());
+    return AGX_OK;
+}
+
+int agx_observe_full(agx_ctx *ctx, float *d_obs, void *stream) {
+    if (!ctx) return AGX_E_INVALID;
+    if (!d_obs) return fail(ctx, AGX_E_INVALID, "agx_observe_full: null buffer");
+    return stack_launch(ctx, 2, nullptr, nullptr, d_obs, stream);
+}
+int agx_get_stack_u8(agx_ctx *ctx, uint8_t *d_out, void *stream) {
+    if (!ctx) return AGX_E_INVALID;
+    if (!d_out) return fail(ctx, AGX_E_INVALID, "agx_get_stack_u8: null buffer");
+    return stack_launch(ctx, 0, nullptr, d_out, nullptr, stream);
+}
+int agx_set_stack_u8(agx_ctx *ctx, const uint8_t *d_in, void *stream) {
+    if (!ctx) return AGX_E_INVALID;
+    if (!d_in) return fail(ctx, AGX_E_INVALID, "agx_set_stack_u8: null buffer");
+    return stack_launch(ctx, 1, d_in, nullptr, nullptr, stream);
+}
+
+// ---------------------------------------------------------------- fovea state
+int agx_fovea_reset(agx_ctx *ctx, const uint8_t *d_mask, void *stream) {
+    if (!ctx) return AGX_E_INVALID;
+    const agx_config &c = ctx->cfg;
+    if (!has_fovea(c)) return fail(ctx, AGX_E_STATE, "agx_fovea_reset: context has no fovea (AGX_KIND_BASE)");
+    DeviceGuard g(c.device);
+    FovResetParams p;
+    p.mask = d_mask;
+    p.loc = ctx->loc[ctx->cur_fov];
+    p.res = ctx->res[ctx->cur_fov];
+    p.init_r = ctx->init_r;
+    p.init_c = ctx->init_c;
+    p.fh = c.fov_h;
+    p.fw = c.fov_w;
+    p.n = c.num_envs;
+    hipLaunchKernelGGL(k_fovea_reset, dim3((c.num_envs + kThreads - 1) / kThreads), dim3(kThreads), 0, S(stream), p);
+    AGX_HIP(ctx, hipGetLastError());
+    return AGX_OK;
+}
+
+int agx_get_fov_state(agx_ctx *ctx, int32_t *d_fov_loc, int32_t *d_fov_res, void *stream) {
+    if (!ctx) return AGX_E_INVALID;
+    const agx_config &c = ctx->cfg;
+    if (!has_fovea(c)) return fail(ctx, AGX_E_STATE, "agx_get_fov_state: context has no fovea");
+    DeviceGuard g(c.device);
+    const size_t b = (size_t)c.num_envs * 2 * sizeof(int32_t);
+    if (d_fov_loc) AGX_HIP(ctx, hipMemcpyAsync(d_fov_loc, ctx->loc[ctx->cur_fov], b, hipMemcpyDeviceToDevice, S(stream)));
+    if (d_fov_res) AGX_HIP(ctx, hipMemcpyAsync(d_fov_res, ctx->res[ctx->cur_fov], b, hipMemcpyDeviceToDevice, S(stream)));
+    return AGX_OK;
+}
+
+int agx_set_fov_state(agx_ctx *ctx, const int32_t *d_fov_loc, const int32_t *d_fov_res, void *stream) {
+    if (!ctx) return AGX_E_INVALID;
+    const agx_config &c = ctx->cfg;
+    if (!has_fovea(c)) return fail(ctx, AGX_E_STATE, "agx_set_fov_state: context has no fovea");
+    DeviceGuard g(c.device);
+    const size_t b = (size_t)c.num_envs * 2 * sizeof(int32_t);
+    if (d_fov_loc) AGX_HIP(ctx, hipMemcpyAsync(ctx->loc[ctx->cur_fov], d_fov_loc, b, hipMemcpyDeviceToDevice, S(stream)));
+    if (d_fov_res) AGX_HIP(ctx, hipMemcpyAsync(ctx->res[ctx->cur_fov], d_fov_res, b, hipMemcpyDeviceToDevice, S(stream)));
+    return AGX_OK;
+}
+
+// ---------------------------------------------------------------- K2/K3/K4
+static int check_dt(agx_ctx *ctx, const void *d_action, int dt) {
+    if (d_action && (dt < AGX_DT_F32 || dt > AGX_DT_I64)) return fail(ctx, AGX_E_INVALID, "unknown action dtype %d", dt);
+    return AGX_OK;
+}
+
+static FovParams fov_params(agx_ctx *ctx, const void *d_action, int dt, const int32_t *d_type, const uint8_t *d_mask,
+                            float *d_obs, int32_t *d_loc, int32_t *d_res) {
+    const agx_config &c = ctx->cfg;
+    FovParams p;
+    p.ring = ctx->ring;
+    p.head = ctx->head[ctx->cur_head];
+    p.loc_in = ctx->loc[ctx->cur_fov];
+    p.loc_out = ctx->loc[ctx->cur_fov ^ 1];
+    p.res_in = ctx->res[ctx->cur_fov];
+    p.res_out = ctx->res[ctx->cur_fov ^ 1];
+    p.action = d_action;
+    p.action_type = d_type;
+    p.mask = d_mask;
+    p.obs = d_obs;
+    p.user_loc = d_loc;
+    p.user_res = d_res;
+    p.xtab = ctx->fx_xtab;
+    p.ytab = ctx->fx_ytab;
+    p.sas_lo = c.sas_lo;
+    p.sas_hi = c.sas_hi;
+    p.action_dt = dt;
+    p.relative = c.action_mode == AGX_MODE_RELATIVE;
+    p.fs = c.frame_stack;
+    p.out_mode = c.out_mode;
+    p.antialias = c.antialias != 0;
+    p.per_h = c.per_h;
+    p.per_w = c.per_w;
+    p.buf1_floats = (int32_t)generic_buf1(c);
+    return p;
+}
+
+int agx_fovea_fixed(agx_ctx *ctx, const void *d_action, int action_dtype, const uint8_t *d_mask, float *d_obs,
+                    int32_t *d_fov_loc, void *stream) {
+    if (!ctx) return AGX_E_INVALID;
+    const agx_config &c = ctx->cfg;
+    if (c.kind != AGX_KIND_FIXED) return fail(ctx, AGX_E_STATE, "agx_fovea_fixed on a context of kind %d", c.kind);
+    if (!d_obs) return fail(ctx, AGX_E_INVALID, "agx_fovea_fixed: null obs buffer");
+    int rc = check_dt(ctx, d_action, action_dtype);
+    if (rc) return rc;
+    DeviceGuard g(c.device);
+    const FovParams p = fov_params(ctx, d_action, action_dtype, nullptr, d_mask, d_obs, d_fov_loc, nullptr);
+    const dim3 grid(c.frame_stack, c.num_envs), block(kThreads);
+    const size_t lds = fixed_lds(c);
+    const bool headline = c.obs_h == 84 && c.obs_w == 84 && c.fov_h == 30 && c.fov_w == 30;
+    using GS = GeomS<84, 84, 30, 30>;
+    const GeomR gr{c.obs_h, c.obs_w, c.fov_h, c.fov_w};
+#define LAUNCH(MODE)                                                                                  \
+    do {                                                                                              \
+        if (headline)                                                                                 \
+            hipLaunchKernelGGL((k_fovea_fixed<GS, MODE>), grid, block, lds, S(stream), GS{}, p);      \
+        else                                                                                          \
+            hipLaunchKernelGGL((k_fovea_fixed<GeomR, MODE>), grid, block, lds, S(stream), gr, p);     \
+    } while (0)
+    switch (c.out_mode) {
+        case AGX_OUT_RAW: LAUNCH(AGX_OUT_RAW); break;
+        case AGX_OUT_MASK: LAUNCH(AGX_OUT_MASK); break;
+        default: LAUNCH(AGX_OUT_RESIZE); break;
+    }
+#undef LAUNCH
+    AGX_HIP(ctx, hipGetLastError());
+    ctx->cur_fov ^= 1;
+    return AGX_OK;
+}
+
+int agx_fovea_peripheral(agx_ctx *ctx, const void *d_action, int action_dtype, const uint8_t *d_mask, float *d_obs,
+                         int32_t *d_fov_loc, void *stream) {
+    if (!ctx) return AGX_E_INVALID;
+    const agx_config &c = ctx->cfg;
+    if (c.kind != AGX_KIND_PERIPHERAL) return fail(ctx, AGX_E_STATE, "agx_fovea_peripheral on a context of kind %d", c.kind);
+    if (!d_obs) return fail(ctx, AGX_E_INVALID, "agx_fovea_peripheral: null obs buffer");
+    int rc = check_dt(ctx, d_action, action_dtype);
+    if (rc) return rc;
+    DeviceGuard g(c.device);
+    const FovParams p = fov_params(ctx, d_action, action_dtype, nullptr, d_mask, d_obs, d_fov_loc, nullptr);
+    const GeomR gr{c.obs_h, c.obs_w, c.fov_h, c.fov_w};
+    hipLaunchKernelGGL((k_fovea_generic<AGX_KIND_PERIPHERAL>), dim3(c.frame_stack, c.num_envs), dim3(kThreads),
+                       generic_lds(c), S(stream), gr, p);
+    AGX_HIP(ctx, hipGetLastError());
+    ctx->cur_fov ^= 1;
+    return AGX_OK;
+}
+
+int agx_fovea_flexible(agx_ctx *ctx, const void *d_action, int action_dtype, const int32_t *d_action_type,
+                       const uint8_t *d_mask, float *d_obs, int32_t *d_fov_loc, int32_t *d_fov_res, void *stream) {
+    if (!ctx) return AGX_E_INVALID;
+    const agx_config &c = ctx->cfg;
+    if (c.kind != AGX_KIND_FLEXIBLE) return fail(ctx, AGX_E_STATE, "agx_fovea_flexible on a context of kind %d", c.kind);
+    if (!d_obs) return fail(ctx, AGX_E_INVALID, "agx_fovea_flexible: null obs buffer");
+    int rc = check_dt(ctx, d_action, action_dtype);
+    if (rc) return rc;
+    DeviceGuard g(c.device);
+    const FovParams p = fov_params(ctx, d_action, action_dtype, d_action_type, d_mask, d_obs, d_fov_loc, d_fov_res);
+    const GeomR gr{c.obs_h, c.obs_w, c.fov_h, c.fov_w};
+    hipLaunchKernelGGL((k_fovea_generic<AGX_KIND_FLEXIBLE>), dim3(c.frame_stack, c.num_envs), dim3(kThreads),
+                       generic_lds(c), S(stream), gr, p);
+    AGX_HIP(ctx, hipGetLastError());
+    ctx->cur_fov ^= 1;
+    return AGX_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,685 @@
+// agx_kernels.h — gfx950 device code of the observation pipeline (HBM-bound
+// byte/float streaming work: no MFMA anywhere, there is no dense contraction).
+//
+//   k_ingest            K1  RGB -> ALE luminance -> OpenCV fixed-point bilinear -> 2-frame max -> u8 ring slot
+//   k_ingest_gray       K1' same append from already obs-sized gray frames
+//   k_stack_u8 / k_full K0  ring -> stack order (u8 / f32 k/255)
+//   k_fovea_fixed       K2  clip/rint sensory action, crop, {raw | mask-out | bilinear upsample}
+//   k_fovea_generic     K3/K4 peripheral squeeze-expand + paste, flexible (ragged) fovea
+//
+// Persistent per-env state (owned by the context, see agx_api.hip):
+//   ring  u8 [N][fs][oh][ow]   numerators k of the reference's float32 k/255 frames
+//   head  i32[2][N]            next slot to write == oldest frame; double-buffered so that the
+//                              several workgroups of one env all read the pre-launch value
+//   loc   i32[2][N][2], res i32[2][N][2]   fov_loc / fov_res, double-buffered for the same reason
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "agx.h"
+#include "agx_taps.h"
+
+namespace agx {
+
+constexpr int kRawH = 210;
+constexpr int kRawW = 160;
+constexpr int kRawRowBytes = kRawW * 3;
+constexpr int kRawFrameBytes = kRawH * kRawRowBytes;
+constexpr int kThreads = 256;
+
+// ---------------------------------------------------------------------------------------------
+// geometry: compile-time for the headline 84x84 / 30x30 configuration, run-time otherwise
+// ---------------------------------------------------------------------------------------------
+template <int OH, int OW, int FH, int FW>
+struct GeomS {
+    __host__ __device__ constexpr int oh() const { return OH; }
+    __host__ __device__ constexpr int ow() const { return OW; }
+    __host__ __device__ constexpr int fh() const { return FH; }
+    __host__ __device__ constexpr int fw() const { return FW; }
+};
+struct GeomR {
+    int oh_, ow_, fh_, fw_;
+    __host__ __device__ int oh() const { return oh_; }
+    __host__ __device__ int ow() const { return ow_; }
+    __host__ __device__ int fh() const { return fh_; }
+    __host__ __device__ int fw() const { return fw_; }
+};
+
+// float32(k)/255 exactly as numpy's `state.astype(np.float32) / 255.` (atari_env.py:75):
+// IEEE correctly-rounded single division (hipcc default -fhip-fp32-correctly-rounded-divide-sqrt;
+// tests/test_gpu_parity.py checks all 256 values bit for bit).
+__device__ __forceinline__ float unit(uint32_t k) { return (float)k / 255.0f; }
+
+// ---------------------------------------------------------------------------------------------
+// K1: ingest
+// ---------------------------------------------------------------------------------------------
+
+// ALE ColourPalette luminance: (uint8) round(r*0.2989 + g*0.5870 + b*0.1140) in C double.
+// The rational value (2989r+5870g+1140b)/10000 decides everything except exact .5 ties, where
+// the double evaluation sometimes lands below the tie (292 of 2^24 inputs); those are replayed
+// in double with the same operation order and no fused multiply-add.
+__device__ __forceinline__ uint32_t ale_lum(uint32_t r, uint32_t g, uint32_t b) {
+    const uint32_t t = 2989u * r + 5870u * g + 1140u * b + 5000u;
+    uint32_t q = t / 10000u;
+    if (__builtin_expect(t - q * 10000u == 0u, 0)) {
+#pragma clang fp contract(off)
+        const double x = ((double)r * 0.2989 + (double)g * 0.5870) + (double)b * 0.1140;
+        const double fl = floor(x);
+        q = (uint32_t)fl + (((x - fl) >= 0.5) ? 1u : 0u);
+    }
+    return q;
+}
+
+struct IngestParams {
+    const uint8_t *frames;   // [N][2][210][160][3]
+    const uint8_t *cmd;      // [N]
+    uint8_t *ring;           // [N][fs][oh][ow]
+    const int32_t *head_in;  // [N]
+    int32_t *head_out;       // [N]
+    const int2 *xtab;        // [ow]  {x0 | x1<<16, a0 | a1<<16}
+    const int4 *ytab;        // [oh]  {y0, y1, b0, b1}
+    int32_t oh, ow, fs;
+    int32_t band_rows;       // output rows per workgroup (band_rows * ow/4 <= 256)
+};
+
+// grid = (bands, N), block = 256.  Per workgroup: the two source rows of each of its output rows,
+// for both frames, go HBM -> registers (12-byte / 4-pixel pieces, lane-contiguous) -> luminance ->
+// LDS as gray bytes; then each thread produces 4 adjacent output pixels and stores one dword.
+__global__ __launch_bounds__(kThreads) void k_ingest(IngestParams p) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int n = blockIdx.y;
+    const int band = blockIdx.x;
+    const int tid = threadIdx.x;
+    const uint32_t cmd = p.cmd[n];
+    const int head = p.head_in[n];
+    const bool skip = (cmd & AGX_CMD_SKIP) != 0;
+    const bool clear = (cmd & AGX_CMD_CLEAR) != 0;
+    if (band == 0 && tid == 0) p.head_out[n] = skip ? head : (clear ? 0 : (head + 1 == p.fs ? 0 : head + 1));
+    if (skip) return;
+    int nvalid = cmd & AGX_CMD_NVALID_MASK;
+    if (nvalid > 2) nvalid = 2;
+    const int slot = clear ? p.fs - 1 : head;
+
+    const int BR = p.band_rows;
+    const int dy0 = band * BR;
+    const int rows = min(BR, p.oh - dy0);
+    int4 *ytab_s = reinterpret_cast<int4 *>(smem);                      // [BR]
+    unsigned char *gray = smem + sizeof(int4) * BR;                       // [2][BR][2][160]
+    if (tid < rows) ytab_s[tid] = p.ytab[dy0 + tid];
+    __syncthreads();
+
+    // phase 1: RGB rows -> gray bytes in LDS
+    constexpr int G4 = kRawW / 4;                                         // 40 four-pixel pieces per row
+    const int ntask = nvalid * rows * 2 * G4;
+    const uint8_t *fbase = p.frames + (size_t)n * 2 * kRawFrameBytes;
+    constexpr int kIter = 8;                                              // 2*12*2*40 / 256 = 7.5
+    for (int base = 0; base < ntask; base += kIter * kThreads) {
+        uint32_t w[kIter][3];
+        int dst[kIter];
+#pragma unroll
+        for (int it = 0; it < kIter; ++it) {
+            const int task = base + it * kThreads + tid;
+            dst[it] = -1;
+            if (task < ntask) {
+                const int rj = task / G4, g4 = task - rj * G4;            // row job = (f, dyl, which)
+                const int f = rj >= 2 * rows ? 1 : 0;                     // nvalid <= 2
+                const int rr = rj - f * 2 * rows;
+                const int dyl = rr >> 1, which = rr & 1;
+                const int4 yt = ytab_s[dyl];
+                const int row = which ? yt.y : yt.x;
+                const uint32_t *src = reinterpret_cast<const uint32_t *>(
+                    fbase + (size_t)f * kRawFrameBytes + (size_t)row * kRawRowBytes + g4 * 12);
+                w[it][0] = src[0];
+                w[it][1] = src[1];
+                w[it][2] = src[2];
+                dst[it] = ((f * BR + dyl) * 2 + which) * kRawW + g4 * 4;
+            }
+        }
+#pragma unroll
+        for (int it = 0; it < kIter; ++it) {
+            if (dst[it] >= 0) {
+                const uint32_t a = w[it][0], b = w[it][1], c = w[it][2];
+                const uint32_t g0 = ale_lum(a & 0xFF, (a >> 8) & 0xFF, (a >> 16) & 0xFF);
+                const uint32_t g1 = ale_lum(a >> 24, b & 0xFF, (b >> 8) & 0xFF);
+                const uint32_t g2 = ale_lum((b >> 16) & 0xFF, b >> 24, c & 0xFF);
+                const uint32_t g3 = ale_lum((c >> 8) & 0xFF, (c >> 16) & 0xFF, c >> 24);
+                *reinterpret_cast<uint32_t *>(gray + dst[it]) = g0 | (g1 << 8) | (g2 << 16) | (g3 << 24);
+            }
+        }
+    }
+    __syncthreads();
+
+    // phase 2: OpenCV fixed-point bilinear + max over the sampled frames
+    const int ow4 = p.ow >> 2;
+    if (tid < rows * ow4) {
+        const int dyl = tid / ow4, xq = tid - dyl * ow4;
+        const int dy = dy0 + dyl;
+        const int4 yt = ytab_s[dyl];
+        const int b0 = yt.z, b1 = yt.w;
+        uint32_t packed = 0;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int2 xt = p.xtab[xq * 4 + k];
+            const int x0 = xt.x & 0xFFFF, x1 = xt.x >> 16;
+            const int a0 = xt.y & 0xFFFF, a1 = xt.y >> 16;
+            int best = 0;
+            for (int f = 0; f < nvalid; ++f) {
+                const unsigned char *r0 = gray + ((f * BR + dyl) * 2) * kRawW;
+                const unsigned char *r1 = r0 + kRawW;
+                const int h0 = (int)r0[x0] * a0 + (int)r0[x1] * a1;
+                const int h1 = (int)r1[x0] * a0 + (int)r1[x1] * a1;
+                const int v = ((((b0 * (h0 >> 4)) >> 16) + ((b1 * (h1 >> 4)) >> 16) + 2) >> 2) & 0xFF;
+                best = max(best, v);
+            }
+            packed |= (uint32_t)best << (8 * k);
+        }
+        const size_t fsz = (size_t)p.oh * p.ow;
+        uint8_t *env = p.ring + (size_t)n * p.fs * fsz;
+        const size_t off = (size_t)dy * p.ow + xq * 4;
+        *reinterpret_cast<uint32_t *>(env + slot * fsz + off) = packed;
+        if (clear)
+            for (int s = 0; s < p.fs - 1; ++s) *reinterpret_cast<uint32_t *>(env + s * fsz + off) = 0u;
+    }
+}
+
+struct IngestGrayParams {
+    const uint8_t *small;    // [N][2][oh][ow]
+    const uint8_t *cmd;
+    uint8_t *ring;
+    const int32_t *head_in;
+    int32_t *head_out;
+    int32_t oh, ow, fs;
+};
+
+// grid = (ceil(oh*ow/4 / 256), N)
+__global__ __launch_bounds__(kThreads) void k_ingest_gray(IngestGrayParams p) {
+    const int n = blockIdx.y;
+    const uint32_t cmd = p.cmd[n];
+    const int head = p.head_in[n];
+    const bool skip = (cmd & AGX_CMD_SKIP) != 0;
+    const bool clear = (cmd & AGX_CMD_CLEAR) != 0;
+    if (blockIdx.x == 0 && threadIdx.x == 0)
+        p.head_out[n] = skip ? head : (clear ? 0 : (head + 1 == p.fs ? 0 : head + 1));
+    if (skip) return;
+    int nvalid = cmd & AGX_CMD_NVALID_MASK;
+    if (nvalid > 2) nvalid = 2;
+    const int slot = clear ? p.fs - 1 : head;
+    const int words = (p.oh * p.ow) >> 2;
+    const int i = blockIdx.x * kThreads + threadIdx.x;
+    if (i >= words) return;
+    const uint32_t *src = reinterpret_cast<const uint32_t *>(p.small) + (size_t)n * 2 * words;
+    uint32_t v = 0;
+    if (nvalid >= 1) v = src[i];
+    if (nvalid >= 2) {
+        const uint32_t u = src[words + i];
+        uint32_t m = 0;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) m |= max((v >> (8 * k)) & 0xFF, (u >> (8 * k)) & 0xFF) << (8 * k);
+        v = m;
+    }
+    uint32_t *env = reinterpret_cast<uint32_t *>(p.ring) + (size_t)n * p.fs * words;
+    env[(size_t)slot * words + i] = v;
+    if (clear)
+        for (int s = 0; s < p.fs - 1; ++s) env[(size_t)s * words + i] = 0u;
+}
+
+// ---------------------------------------------------------------------------------------------
+// K0: stack-order views of the ring
+// ---------------------------------------------------------------------------------------------
+struct StackParams {
+    uint8_t *ring;
+    int32_t *head;           // current head (read), or written by k_set_stack
+    const uint8_t *in_u8;
+    uint8_t *out_u8;
+    float *out_f32;
+    int32_t words, fs;       // words = oh*ow/4
+};
+
+// grid = (ceil(words/256), fs, N)
+__global__ __launch_bounds__(kThreads) void k_stack_u8(StackParams p) {
+    const int n = blockIdx.z, j = blockIdx.y;
+    const int i = blockIdx.x * kThreads + threadIdx.x;
+    if (i >= p.words) return;
+    int slot = p.head[n] + j;
+    if (slot >= p.fs) slot -= p.fs;
+    const uint32_t *src = reinterpret_cast<const uint32_t *>(p.ring) + ((size_t)n * p.fs + slot) * p.words;
+    reinterpret_cast<uint32_t *>(p.out_u8)[((size_t)n * p.fs + j) * p.words + i] = src[i];
+}
+
+__global__ __launch_bounds__(kThreads) void k_set_stack(StackParams p) {
+    const int n = blockIdx.z, j = blockIdx.y;
+    const int i = blockIdx.x * kThreads + threadIdx.x;
+    if (i == 0 && j == 0) p.head[n] = 0;
+    if (i >= p.words) return;
+    const size_t o = ((size_t)n * p.fs + j) * p.words + i;
+    reinterpret_cast<uint32_t *>(p.ring)[o] = reinterpret_cast<const uint32_t *>(p.in_u8)[o];
+}
+
+__global__ __launch_bounds__(kThreads) void k_full(StackParams p) {
+    const int n = blockIdx.z, j = blockIdx.y;
+    const int i = blockIdx.x * kThreads + threadIdx.x;
+    if (i >= p.words) return;
+    int slot = p.head[n] + j;
+    if (slot >= p.fs) slot -= p.fs;
+    const uint32_t v = (reinterpret_cast<const uint32_t *>(p.ring) + ((size_t)n * p.fs + slot) * p.words)[i];
+    float4 o;
+    o.x = unit(v & 0xFF);
+    o.y = unit((v >> 8) & 0xFF);
+    o.z = unit((v >> 16) & 0xFF);
+    o.w = unit(v >> 24);
+    reinterpret_cast<float4 *>(p.out_f32)[((size_t)n * p.fs + j) * p.words + i] = o;
+}
+
+// ---------------------------------------------------------------------------------------------
+// sensory action -> fov_loc   (fov_env.py:166-170,187-199; flexible: :270-271,300-324)
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ double load_action(const void *p, int dt, size_t i) {
+    switch (dt) {
+        case AGX_DT_F32: return (double)static_cast<const float *>(p)[i];
+        case AGX_DT_F64: return static_cast<const double *>(p)[i];
+        case AGX_DT_I32: return (double)static_cast<const int32_t *>(p)[i];
+        default: return (double)static_cast<const int64_t *>(p)[i];
+    }
+}
+
+// np.rint(np.clip(x, lo, hi)).astype(int); NaN is normalised to lo (the reference is undefined there)
+__device__ __forceinline__ int clip_rint(double x, double lo, double hi) {
+    x = fmax(x, lo);
+    x = fmin(x, hi);
+    return (int)rint(x);
+}
+
+struct FovParams {
+    const uint8_t *ring;
+    const int32_t *head;
+    const int32_t *loc_in;
+    int32_t *loc_out;
+    const int32_t *res_in;      // flexible only
+    int32_t *res_out;
+    const void *action;         // [N][2] or nullptr
+    const int32_t *action_type; // flexible only, may be nullptr
+    const uint8_t *mask;        // [N] or nullptr
+    float *obs;
+    int32_t *user_loc;          // may be nullptr
+    int32_t *user_res;          // may be nullptr
+    const Tap *xtab;            // fixed/resize: [ow] lin2 taps fov_w -> obs_w
+    const Tap *ytab;            // fixed/resize: [oh] lin2 taps fov_h -> obs_h
+    double sas_lo, sas_hi;
+    int32_t action_dt;
+    int32_t relative;
+    int32_t fs;
+    int32_t out_mode;
+    int32_t antialias;
+    int32_t per_h, per_w;
+    int32_t buf1_floats;        // generic kernels: size of the second LDS buffer (multiple of 4)
+};
+
+__device__ __forceinline__ void next_loc(const FovParams &p, int n, int bound_r, int bound_c, int &r, int &c) {
+    r = p.loc_in[2 * n];
+    c = p.loc_in[2 * n + 1];
+    if (p.action) {
+        const double ar = load_action(p.action, p.action_dt, 2 * (size_t)n);
+        const double ac = load_action(p.action, p.action_dt, 2 * (size_t)n + 1);
+        if (p.relative) {
+            const int dr = clip_rint(ar, p.sas_lo, p.sas_hi);
+            const int dc = clip_rint(ac, p.sas_lo, p.sas_hi);
+            r = clip_rint((double)(r + dr), 0.0, (double)bound_r);
+            c = clip_rint((double)(c + dc), 0.0, (double)bound_c);
+        } else {
+            r = clip_rint(ar, 0.0, (double)bound_r);
+            c = clip_rint(ac, 0.0, (double)bound_c);
+        }
+    }
+}
+
+// Stage the window [r, r+h) x [c, c+w) of one u8 frame (row pitch ow, ow % 4 == 0) into LDS as
+// float32 k/255, tight pitch w.  Aligned dword loads; each thread peels the bytes it owns.
+__device__ __forceinline__ void stage_window(const uint8_t *frame, int ow, int r, int c, int h, int w,
+                                             float *dst, int tid) {
+    const int c4 = c & ~3;
+    const int wpr = ((c - c4) + w + 3) >> 2;          // dwords per row
+    const int ntask = h * wpr;
+    for (int task = tid; task < ntask; task += kThreads) {
+        const int y = task / wpr, q = task - y * wpr;
+        const int col = c4 + 4 * q;
+        const uint32_t v = *reinterpret_cast<const uint32_t *>(frame + (size_t)(r + y) * ow + col);
+#pragma unroll
+        for (int b = 0; b < 4; ++b) {
+            const int x = col + b - c;
+            if (x >= 0 && x < w) dst[y * w + x] = unit((v >> (8 * b)) & 0xFF);
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// K2: FixedFovealEnv
+// grid = (fs, N): one workgroup per (env, stacked frame); block = 256
+//   MODE = AGX_OUT_RESIZE: LDS s[fh][fw] -> H[fh][ow] (horizontal lerp) -> float4 rows of the
+//          84x84 output = vertical lerp of two ds_read_b128; every store is 16 B/lane, lane-linear.
+// ---------------------------------------------------------------------------------------------
+template <class G, int MODE>
+__global__ __launch_bounds__(kThreads) void k_fovea_fixed(G g, FovParams p) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int j = blockIdx.x, n = blockIdx.y, tid = threadIdx.x;
+    const int oh = g.oh(), ow = g.ow(), fh = g.fh(), fw = g.fw();
+    if (p.mask && !p.mask[n]) {
+        if (j == 0 && tid < 2) p.loc_out[2 * n + tid] = p.loc_in[2 * n + tid];
+        return;
+    }
+    int r, c;
+    next_loc(p, n, oh - fh, ow - fw, r, c);
+    if (j == 0 && tid == 0) {
+        p.loc_out[2 * n] = r;
+        p.loc_out[2 * n + 1] = c;
+        if (p.user_loc) {
+            p.user_loc[2 * n] = r;
+            p.user_loc[2 * n + 1] = c;
+        }
+    }
+    int slot = p.head[n] + j;
+    if (slot >= p.fs) slot -= p.fs;
+    const size_t fsz = (size_t)oh * ow;
+    const uint8_t *frame = p.ring + ((size_t)n * p.fs + slot) * fsz;
+
+    float *s = reinterpret_cast<float *>(smem);                      // [fh][fw]
+    stage_window(frame, ow, r, c, fh, fw, s, tid);
+    __syncthreads();
+
+    if (MODE == AGX_OUT_RAW) {
+        float *out = p.obs + ((size_t)n * p.fs + j) * (size_t)(fh * fw);
+        for (int i = tid; i < fh * fw; i += kThreads) out[i] = s[i];
+        return;
+    }
+    const int ow4 = ow >> 2;
+    float4 *out4 = reinterpret_cast<float4 *>(p.obs) + ((size_t)n * p.fs + j) * (size_t)(oh * ow4);
+    if (MODE == AGX_OUT_MASK) {
+        for (int q = tid; q < oh * ow4; q += kThreads) {
+            const int row = q / ow4, x = (q - row * ow4) * 4;
+            const int y = row - r;
+            float v[4] = {0.f, 0.f, 0.f, 0.f};
+            if (y >= 0 && y < fh) {
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const int xx = x + k - c;
+                    if (xx >= 0 && xx < fw) v[k] = s[y * fw + xx];
+                }
+            }
+            out4[q] = make_float4(v[0], v[1], v[2], v[3]);
+        }
+        return;
+    }
+    // AGX_OUT_RESIZE
+    const int s_floats = (fh * fw + 3) & ~3;
+    float *H = s + s_floats;                                          // [fh][ow], 16-B aligned rows
+    for (int i = tid; i < fh * ow; i += kThreads) {
+        const int y = i / ow, x = i - y * ow;
+        const Tap t = p.xtab[x];
+        H[i] = t.a * s[y * fw + t.lo] + t.b * s[y * fw + t.aux];
+    }
+    __syncthreads();
+    const float4 *H4 = reinterpret_cast<const float4 *>(H);
+    for (int q = tid; q < oh * ow4; q += kThreads) {
+        const int row = q / ow4, x4 = q - row * ow4;
+        const Tap t = p.ytab[row];
+        const float4 a = H4[t.lo * ow4 + x4];
+        const float4 b = H4[t.aux * ow4 + x4];
+        float4 o;
+        o.x = t.a * a.x + t.b * b.x;
+        o.y = t.a * a.y + t.b * b.y;
+        o.z = t.a * a.z + t.b * b.z;
+        o.w = t.a * a.w + t.b * b.w;
+        out4[q] = o;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// generic separable resample pass inside one workgroup (K3 / K4)
+// ---------------------------------------------------------------------------------------------
+struct PassDesc {
+    int n_in, n_out;
+    bool aa;         // antialiased down-scale (n_in > n_out and antialias on)
+    float inv;       // aa: 1/scale
+};
+
+__device__ __forceinline__ PassDesc make_pass(int n_in, int n_out, int antialias) {
+    PassDesc d;
+    d.n_in = n_in;
+    d.n_out = n_out;
+    d.aa = antialias && n_in > n_out;
+    d.inv = d.aa ? (float)((double)n_out / (double)n_in) : 1.f;
+    return d;
+}
+
+__device__ __forceinline__ void build_taps(const PassDesc &d, Tap *tab, int tid) {
+    for (int i = tid; i < d.n_out; i += kThreads) {
+        float inv;
+        tab[i] = d.aa ? make_tap_aa(i, d.n_in, d.n_out, &inv) : make_tap_lin2(i, d.n_in, d.n_out);
+    }
+}
+
+// element of a pass: src walks with `stride` floats between consecutive taps
+__device__ __forceinline__ float apply_tap(const PassDesc &d, const Tap &t, const float *src, int stride) {
+    if (!d.aa) return t.a * src[t.lo * stride] + t.b * src[t.aux * stride];
+    float acc = 0.f;
+    const float *q = src + t.lo * stride;
+    for (int k = 0; k < t.aux; ++k) {
+        float x = ((float)k - t.a + 0.5f) * d.inv;
+        x = fabsf(x);
+        const float w = x < 1.f ? 1.f - x : 0.f;
+        acc += w * q[k * stride];
+    }
+    return acc * t.b;
+}
+
+// dst[rows][n_out] = resample along W of src[rows][n_in]
+__device__ __forceinline__ void pass_w(const PassDesc &d, const Tap *tab, const float *src, float *dst,
+                                       int rows, int tid) {
+    const int total = rows * d.n_out;
+    for (int i = tid; i < total; i += kThreads) {
+        const int y = i / d.n_out, x = i - y * d.n_out;
+        dst[i] = apply_tap(d, tab[x], src + y * d.n_in, 1);
+    }
+}
+
+// dst[n_out][cols] = resample along H of src[n_in][cols]
+__device__ __forceinline__ void pass_h(const PassDesc &d, const Tap *tab, const float *src, float *dst,
+                                       int cols, int tid) {
+    const int total = d.n_out * cols;
+    for (int i = tid; i < total; i += kThreads) {
+        const int y = i / cols, x = i - y * cols;
+        dst[i] = apply_tap(d, tab[y], src + x, cols);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// K3: FixedFovealPeripheralEnv, K4: FlexibleFovealEnv.  grid = (fs, N), block = 256.
+// LDS: buf0, buf1 (oh*ow floats each), tab (max(oh,ow,..) taps)
+// ---------------------------------------------------------------------------------------------
+template <int KIND>
+__global__ __launch_bounds__(kThreads) void k_fovea_generic(GeomR g, FovParams p) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int j = blockIdx.x, n = blockIdx.y, tid = threadIdx.x;
+    const int oh = g.oh(), ow = g.ow(), fh = g.fh(), fw = g.fw();
+    const bool flex = KIND == AGX_KIND_FLEXIBLE;
+    if (p.mask && !p.mask[n]) {
+        if (j == 0 && tid < 2) {
+            p.loc_out[2 * n + tid] = p.loc_in[2 * n + tid];
+            if (flex) p.res_out[2 * n + tid] = p.res_in[2 * n + tid];
+        }
+        return;
+    }
+    // ---- state update
+    int rh = fh, rw = fw, r, c;
+    if (flex) {
+        rh = p.res_in[2 * n];
+        rw = p.res_in[2 * n + 1];
+        const int type = (p.action && p.action_type) ? p.action_type[n] : AGX_FOV_LOC;
+        if (p.action && type == AGX_FOV_RES) {
+            rh = clip_rint(load_action(p.action, p.action_dt, 2 * (size_t)n), 1.0, (double)oh);
+            rw = clip_rint(load_action(p.action, p.action_dt, 2 * (size_t)n + 1), 1.0, (double)ow);
+            r = clip_rint((double)p.loc_in[2 * n], 0.0, (double)(oh - rh));
+            c = clip_rint((double)p.loc_in[2 * n + 1], 0.0, (double)(ow - rw));
+        } else {
+            next_loc(p, n, oh - rh, ow - rw, r, c);
+        }
+    } else {
+        next_loc(p, n, oh - fh, ow - fw, r, c);
+    }
+    if (j == 0 && tid == 0) {
+        p.loc_out[2 * n] = r;
+        p.loc_out[2 * n + 1] = c;
+        if (p.user_loc) {
+            p.user_loc[2 * n] = r;
+            p.user_loc[2 * n + 1] = c;
+        }
+        if (flex) {
+            p.res_out[2 * n] = rh;
+            p.res_out[2 * n + 1] = rw;
+            if (p.user_res) {
+                p.user_res[2 * n] = rh;
+                p.user_res[2 * n + 1] = rw;
+            }
+        }
+    }
+    int slot = p.head[n] + j;
+    if (slot >= p.fs) slot -= p.fs;
+    const size_t fsz = (size_t)oh * ow;
+    const uint8_t *frame = p.ring + ((size_t)n * p.fs + slot) * fsz;
+    const int cap = (oh * ow + 3) & ~3;
+    float *buf0 = reinterpret_cast<float *>(smem);
+    float *buf1 = buf0 + cap;
+    Tap *tab = reinterpret_cast<Tap *>(buf1 + p.buf1_floats);
+    const int ow4 = ow >> 2;
+    float4 *out4 = reinterpret_cast<float4 *>(p.obs) + ((size_t)n * p.fs + j) * (size_t)(oh * ow4);
+
+    if (KIND == AGX_KIND_PERIPHERAL) {
+        // S = full frame; periphery = expand(squeeze(S)); fovea pasted at full resolution
+        const int ph = p.per_h, pw = p.per_w;
+        float *S = buf0;
+        stage_window(frame, ow, 0, 0, oh, ow, S, tid);
+        // the three intermediates share buf1: A[oh][pw] | B[ph][pw] | C[ph][ow]
+        float *A = buf1;
+        float *B = A + oh * pw;
+        float *C = B + ph * pw;
+        const bool same = (ph == oh && pw == ow);           // torchvision returns the input unchanged
+        PassDesc d = make_pass(ow, pw, p.antialias);
+        build_taps(d, tab, tid);
+        __syncthreads();
+        pass_w(d, tab, S, A, oh, tid);
+        __syncthreads();
+        d = make_pass(oh, ph, p.antialias);
+        build_taps(d, tab, tid);
+        __syncthreads();
+        pass_h(d, tab, A, B, pw, tid);
+        __syncthreads();
+        d = make_pass(pw, ow, p.antialias);
+        build_taps(d, tab, tid);
+        __syncthreads();
+        pass_w(d, tab, B, C, ph, tid);
+        __syncthreads();
+        d = make_pass(ph, oh, p.antialias);
+        build_taps(d, tab, tid);
+        __syncthreads();
+        for (int q = tid; q < oh * ow4; q += kThreads) {
+            const int row = q / ow4, x = (q - row * ow4) * 4;
+            const Tap t = tab[row];
+            const bool in_r = row >= r && row < r + fh;
+            float v[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const int xx = x + k;
+                if (same || (in_r && xx >= c && xx < c + fw))
+                    v[k] = S[row * ow + xx];
+                else
+                    v[k] = apply_tap(d, t, C + xx, ow);
+            }
+            out4[q] = make_float4(v[0], v[1], v[2], v[3]);
+        }
+        return;
+    }
+
+    // ---- flexible
+    float *cur = buf0, *oth = buf1;
+    stage_window(frame, ow, r, c, rh, rw, cur, tid);
+    __syncthreads();
+    if (rh > fh) {                                           // rows only, fov_env.py:286
+        // Resize(fov_size) then Resize(fov_res): [rh][rw] -> [rh][fw] -> [fh][fw] -> [fh][rw] -> [rh][rw]
+        PassDesc d = make_pass(rw, fw, p.antialias);
+        build_taps(d, tab, tid);
+        __syncthreads();
+        pass_w(d, tab, cur, oth, rh, tid);
+        __syncthreads();
+        d = make_pass(rh, fh, p.antialias);
+        build_taps(d, tab, tid);
+        __syncthreads();
+        pass_h(d, tab, oth, cur, fw, tid);
+        __syncthreads();
+        d = make_pass(fw, rw, p.antialias);
+        build_taps(d, tab, tid);
+        __syncthreads();
+        pass_w(d, tab, cur, oth, fh, tid);
+        __syncthreads();
+        d = make_pass(fh, rh, p.antialias);
+        build_taps(d, tab, tid);
+        __syncthreads();
+        pass_h(d, tab, oth, cur, rw, tid);
+        __syncthreads();
+    }
+    if (p.out_mode == AGX_OUT_RESIZE && !(rh == oh && rw == ow)) {
+        PassDesc d = make_pass(rw, ow, p.antialias);         // res <= obs: never a down-scale
+        build_taps(d, tab, tid);
+        __syncthreads();
+        pass_w(d, tab, cur, oth, rh, tid);                   // [rh][ow]
+        __syncthreads();
+        d = make_pass(rh, oh, p.antialias);
+        build_taps(d, tab, tid);
+        __syncthreads();
+        const float4 *H4 = reinterpret_cast<const float4 *>(oth);
+        for (int q = tid; q < oh * ow4; q += kThreads) {
+            const int row = q / ow4, x4 = q - row * ow4;
+            const Tap t = tab[row];
+            const float4 a = H4[t.lo * ow4 + x4];
+            const float4 b = H4[t.aux * ow4 + x4];
+            out4[q] = make_float4(t.a * a.x + t.b * b.x, t.a * a.y + t.b * b.y,
+                                  t.a * a.z + t.b * b.z, t.a * a.w + t.b * b.w);
+        }
+        return;
+    }
+    // mask-out paste at (r, c); raw (padded, window at the origin); resize with res == obs (identity)
+    const int pr = (p.out_mode == AGX_OUT_MASK) ? r : 0;
+    const int pc = (p.out_mode == AGX_OUT_MASK) ? c : 0;
+    for (int q = tid; q < oh * ow4; q += kThreads) {
+        const int row = q / ow4, x = (q - row * ow4) * 4;
+        const int y = row - pr;
+        float v[4] = {0.f, 0.f, 0.f, 0.f};
+        if (y >= 0 && y < rh) {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const int xx = x + k - pc;
+                if (xx >= 0 && xx < rw) v[k] = cur[y * rw + xx];
+            }
+        }
+        out4[q] = make_float4(v[0], v[1], v[2], v[3]);
+    }
+}
+
+// fov_loc / fov_res (re)initialisation for masked envs (fov_env.py:149-150,250-251)
+struct FovResetParams {
+    const uint8_t *mask;
+    int32_t *loc;
+    int32_t *res;     // may be nullptr
+    int32_t init_r, init_c, fh, fw, n;
+};
+__global__ __launch_bounds__(kThreads) void k_fovea_reset(FovResetParams p) {
+    const int n = blockIdx.x * kThreads + threadIdx.x;
+    if (n >= p.n) return;
+    if (p.mask && !p.mask[n]) return;
+    p.loc[2 * n] = p.init_r;
+    p.loc[2 * n + 1] = p.init_c;
+    if (p.res) {
+        p.res[2 * n] = p.fh;
+        p.res[2 * n + 1] = p.fw;
+    }
+}
+
+}  // namespace agx

@@ -1,0 +1,244 @@
+#!/usr/bin/env python3
+"""bench.py — env steps/sec of the batched active-vision observation path on MI355X.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W]
+
+A "step" is one pass of the hot path over one batch of synthetic input that is
+already resident in HBM: K1 ingest (2 raw RGB frames per env -> gray -> OpenCV
+fixed-point resize -> 2-frame max -> frame-stack ring) followed by the fovea
+kernel (sensory action -> crop -> bilinear resize to 84x84, f32 out).
+Workload = BASELINE.json configs[1]: 1024x AtariFixedFovealEnv per GPU, 84x84 obs,
+30x30 fovea, frame_stack=4, action_repeat=4 (=> two sampled frames per step).
+
+For N>1 the driver launches one rank per GPU via torch.distributed.run; envs shard
+by contiguous index blocks, there is no data-path collective (weak scaling).
+Prints ONE JSON line on rank 0.
+"""
+import argparse
+import json
+import os
+import subprocess
+import sys
+import time
+
+REPO = os.path.dirname(os.path.abspath(__file__))
+for _p in (REPO, os.path.join(REPO, "active-gym_amd")):
+    if _p not in sys.path:
+        sys.path.insert(0, _p)
+
+HBM_PEAK_GBS = 8000.0      # MI355X HBM3E spec peak (/opt/skills/guides/MI355X_MICROARCH.md)
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=300)
+    ap.add_argument("--warmup", type=int, default=30)
+    ap.add_argument("--envs", type=int, default=1024, help="envs per GPU")
+    ap.add_argument("--kind", default="fixed", choices=["fixed", "peripheral", "flexible"])
+    ap.add_argument("--pool", type=int, default=8, help="distinct synthetic input batches cycled through")
+    ap.add_argument("--cpu-seconds", type=float, default=12.0, help="budget of the CPU-baseline sample")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-events", action="store_true", help="skip per-kernel HIP events in the timed region")
+    return ap.parse_args()
+
+
+def synth_inputs(torch, dev, n, pool, seed):
+    """Synthetic Atari-shaped inputs: i.i.d. uniform u8 RGB frames, 0.1% of env-steps
+    with fewer than two sampled frames, 0.1% full resets, absolute actions uniform in [-5, 60)."""
+    g = torch.Generator(device=dev)
+    g.manual_seed(seed)
+    frames, cmds, acts = [], [], []
+    for _ in range(pool):
+        frames.append(torch.randint(0, 256, (n, 2, 210, 160, 3), dtype=torch.uint8, device=dev, generator=g))
+        u = torch.rand((n,), device=dev, generator=g)
+        nvalid = torch.full((n,), 2, dtype=torch.uint8, device=dev)
+        nvalid[u < 0.001] = 1
+        nvalid[u < 0.0005] = 0
+        reset = torch.rand((n,), device=dev, generator=g) < 0.001
+        cmd = torch.where(reset, torch.tensor(1 | 0x04, dtype=torch.uint8, device=dev), nvalid)
+        cmds.append(cmd.contiguous())
+        acts.append((torch.rand((n, 2), device=dev, generator=g) * 65.0 - 5.0).contiguous())
+    return frames, cmds, acts
+
+
+def make_pipeline(kind, n, dev):
+    from active_gym import ObsPipeline
+    kw = dict(num_envs=n, obs_size=(84, 84), frame_stack=4, fov_size=(30, 30), fov_init_loc=(0, 0),
+              sensory_action_mode="absolute", device=dev)
+    if kind == "fixed":
+        return ObsPipeline(kind="fixed", resize_to_full=True, **kw)
+    if kind == "peripheral":
+        return ObsPipeline(kind="peripheral", peripheral_res=(20, 20), antialias=True, **kw)
+    return ObsPipeline(kind="flexible", resize_to_full=True, antialias=True, **kw)
+
+
+def cpu_baseline(budget_s, seed):
+    """The oracle (a per-env CPU port of the reference's NumPy/OpenCV/torchvision arithmetic) timed on
+    this box's host cores over a bounded sample of the same workload."""
+    import numpy as np
+    from oracle import oracle as O
+    try:
+        from oracle import cport
+        have_c = cport.available()
+    except Exception:
+        cport, have_c = None, False
+    rng = np.random.default_rng(seed)
+    n = 16
+    frames = rng.integers(0, 256, (n, 2, 210, 160, 3), dtype=np.uint8)
+    acts = rng.uniform(-5, 60, (n, 2))
+    kw = dict(obs_size=(84, 84), fov_size=(30, 30), fov_init_loc=(0, 0), sensory_action_mode="absolute",
+              resize_to_full=True)
+
+    if have_c:
+        runner = cport.EnvBatch(n, frame_stack=4)
+
+        def one_pass():
+            runner.step_fixed(frames, acts)
+        impl = "oracle/cport.c (C, -O2, single thread)"
+    else:
+        ring = O.RingOracle(n, 4, (84, 84))
+        fov = [O.FixedFovealOracle(**kw) for _ in range(n)]
+
+        def one_pass():
+            ring.ingest(frames, np.full(n, 2))
+            full = ring.full_state()
+            for i in range(n):
+                fov[i].step(full[i], acts[i])
+        impl = "oracle/oracle.py (NumPy, single thread)"
+    one_pass()
+    t0 = time.perf_counter()
+    one_pass()
+    dt = time.perf_counter() - t0
+    reps = max(1, min(2000, int(budget_s / max(dt, 1e-6))))
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        one_pass()
+    el = time.perf_counter() - t0
+    return {"value": n * reps / el, "unit": "env steps/s", "cores": 1, "kind": "port",
+            "sample": f"{n} envs x {reps} steps of the same config through {impl}, {el:.1f} s"}
+
+
+def relaunch_under_torchrun(args):
+    """`python bench.py --gpus N` without a launcher: start the ranks as a child job (nothing here has
+    touched the GPU yet) and exit with its code."""
+    port = 29500 + (os.getpid() % 2000)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    sys.exit(subprocess.call(cmd))
+
+
+def main():
+    args = parse()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus > 1 and world == 1:
+        relaunch_under_torchrun(args)
+    import torch
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a ROCm GPU (the observation path has no CPU implementation)")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group("nccl", device_id=dev)
+
+    n = args.envs
+    pipe = make_pipeline(args.kind, n, dev)
+    frames, cmds, acts = synth_inputs(torch, dev, n, args.pool, 1234 + rank)
+    types = None
+    if args.kind == "flexible":
+        g = torch.Generator(device=dev)
+        g.manual_seed(99 + rank)
+        types = [torch.randint(0, 2, (n,), dtype=torch.int32, device=dev, generator=g) for _ in range(args.pool)]
+        for i in range(args.pool):       # FOV_RES actions carry integer resolutions in [10, 60]
+            res = torch.randint(10, 61, (n, 2), device=dev, generator=g).float()
+            acts[i] = torch.where(types[i][:, None] == 1, res, acts[i]).contiguous()
+    obs = torch.empty(pipe.obs_shape, dtype=torch.float32, device=dev)
+    loc = torch.empty((n, 2), dtype=torch.int32, device=dev)
+    res_out = torch.empty((n, 2), dtype=torch.int32, device=dev)
+
+    def step(k):
+        i = k % args.pool
+        pipe.ingest(frames[i], cmds[i])
+        if types is None:
+            pipe.fovea(acts[i], out=obs, loc_out=loc)
+        else:
+            pipe.fovea(acts[i], action_type=types[i], out=obs, loc_out=loc, res_out=res_out)
+
+    def barrier():
+        if dist is not None:
+            dist.barrier(device_ids=[local_rank])
+
+    for k in range(args.warmup):
+        step(k)
+    K = args.steps
+    use_ev = not args.no_events
+    ev = [[torch.cuda.Event(enable_timing=True) for _ in range(3)] for _ in range(K)] if use_ev else None
+    barrier()
+    torch.cuda.synchronize(dev)
+    t0 = time.perf_counter()
+    if use_ev:
+        # same launches as step(), bracketed by HIP events on the launch stream
+        for k in range(K):
+            i = k % args.pool
+            e = ev[k]
+            e[0].record()
+            pipe.ingest(frames[i], cmds[i])
+            e[1].record()
+            if types is None:
+                pipe.fovea(acts[i], out=obs, loc_out=loc)
+            else:
+                pipe.fovea(acts[i], action_type=types[i], out=obs, loc_out=loc, res_out=res_out)
+            e[2].record()
+    else:
+        for k in range(K):
+            step(k)
+    torch.cuda.synchronize(dev)
+    elapsed = time.perf_counter() - t0
+    barrier()
+    if dist is not None:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    out = None
+    if rank == 0:
+        total_envs = n * world
+        ms_per_step = elapsed / K * 1e3
+        kernels = {}
+        roof = None
+        if use_ev:
+            t_ing = sum(e[0].elapsed_time(e[1]) for e in ev) / K * 1e-3
+            t_fov = sum(e[1].elapsed_time(e[2]) for e in ev) / K * 1e-3
+            for name, key, t in (("k_ingest", "ingest", t_ing), ("k_fovea_" + args.kind, "fovea", t_fov)):
+                b = pipe.algorithmic_bytes(key)
+                kernels[name] = {"avg_us": t * 1e6, "algorithmic_bytes": b, "achieved_GBps": b / t / 1e9,
+                                 "frac": b / t / 1e9 / HBM_PEAK_GBS}
+            dom = max(kernels, key=lambda k_: kernels[k_]["avg_us"])
+            roof = {"bound": "hbm", "kernel": dom, "achieved": kernels[dom]["achieved_GBps"], "peak": HBM_PEAK_GBS,
+                    "unit": "GB/s", "frac": kernels[dom]["frac"], "traffic": None,
+                    "avg_launch_us": kernels[dom]["avg_us"], "algorithmic_bytes_per_launch": kernels[dom]["algorithmic_bytes"]}
+        out = {
+            "metric": "env steps/sec at N=1024 AtariFixedFovealEnv; 1/2/4/8-GPU scaling",
+            "value": total_envs * K / elapsed, "unit": "env steps/s", "n_gpus": world, "steps": K, "warmup": args.warmup,
+            "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "u8 ingest / f32 resize", "data": "synthetic",
+            "config": {"workload": f"{n}x AtariFixedFovealEnv-shaped envs per GPU (kind={args.kind}), 84x84 obs, 30x30 fov, "
+                                   "frame_stack=4, action_repeat=4, resize_to_full, absolute sensory actions; "
+                                   "device-resident synthetic RGB frames (BASELINE.json configs[1])",
+                       "envs_per_gpu": n, "total_envs": total_envs, "input_pool": args.pool,
+                       "parallelism": f"env-shard x{world}, no collective"},
+            "roofline": roof, "kernels": kernels,
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(args.cpu_seconds, 1234)
+        print(json.dumps(out), flush=True)
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,60 @@
+"""CPU: the C-ABI library builds for gfx950, loads without a GPU, and exports
+exactly the symbols include/agx.h declares (no compute calls here)."""
+import ctypes
+import importlib.util
+import os
+import re
+
+import pytest
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _build():
+    spec = importlib.util.spec_from_file_location("agx_build", os.path.join(REPO, "active-gym_amd", "build.py"))
+    m = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(m)
+    return m.build()
+
+
+def _declared():
+    src = open(os.path.join(REPO, "include", "agx.h")).read()
+    return sorted(set(re.findall(r"^AGX_API[^;(]*?\b(agx_\w+)\s*\(", src, flags=re.M)))
+
+
+def test_header_declares_the_expected_surface():
+    names = _declared()
+    assert len(names) == 17 and "agx_ingest" in names and "agx_fovea_flexible" in names
+
+
+def test_library_exports_every_declared_symbol():
+    path = _build()
+    handle = ctypes.CDLL(path)
+    for name in _declared():
+        assert hasattr(handle, name), name
+    assert handle.agx_abi_version() == 1
+
+
+def test_binding_matches_header():
+    from active_gym import _native as nat
+    assert sorted(nat.SIGNATURES) == _declared()
+    _build()
+    lib = nat.lib()
+    assert lib.agx_abi_version() == nat.ABI_VERSION
+    assert ctypes.sizeof(nat.AgxConfig) == 96
+
+
+def test_create_fails_loudly_without_gpu_or_bad_config():
+    import torch
+    from active_gym import _native as nat
+    _build()
+    lib = nat.lib()
+    cfg = nat.AgxConfig()
+    cfg.struct_size = 4            # wrong on purpose: rejected before any HIP call
+    ctx = ctypes.c_void_p()
+    rc = lib.agx_create(ctypes.byref(cfg), ctypes.byref(ctx))
+    assert rc == nat.E_INVALID and "struct_size" in nat.last_error(None) and not ctx.value
+    if not torch.cuda.is_available():
+        from active_gym import ObsPipeline
+        with pytest.raises(RuntimeError, match="no CPU implementation"):
+            ObsPipeline(4, "fixed", fov_size=(30, 30))

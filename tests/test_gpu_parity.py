@@ -1,0 +1,410 @@
+"""GPU parity tests proper: the HIP path (through the C ABI) against the CPU
+oracle on the same seeded inputs, against the committed golden vectors, and —
+at the benchmark's full size — through size-independent properties.
+
+Bars: integer / byte / index work bit-exact; float resize within 1e-5
+(BASELINE.json north_star)."""
+import numpy as np
+import pytest
+import torch
+
+from golden_util import fovea_case_names, load_fovea, unit64
+from oracle import oracle as O
+
+pytestmark = pytest.mark.gpu
+FLOAT_TOL = 1e-5
+
+
+@pytest.fixture(scope="module")
+def dev():
+    return torch.device("cuda:0")
+
+
+def _pipe(**kw):
+    from active_gym import ObsPipeline
+    return ObsPipeline(**kw)
+
+
+def _t(x, dev, dtype=None):
+    t = torch.from_numpy(np.ascontiguousarray(x))
+    if dtype is not None:
+        t = t.to(dtype)
+    return t.to(dev)
+
+
+def test_native_library_is_loaded():
+    from active_gym import _native as nat
+    lib = nat.lib()
+    assert lib.agx_abi_version() == 1
+    maps = open("/proc/self/maps").read()
+    assert "libagx.so" in maps
+
+
+# ---------------------------------------------------------------- K0 / unit conversion
+def test_unit_division_all_256_values_bit_exact(dev):
+    p = _pipe(num_envs=1, kind="base", obs_size=(16, 16), frame_stack=1)
+    st = np.arange(256, dtype=np.uint8).reshape(1, 1, 16, 16)
+    p.set_stack_u8(_t(st, dev))
+    got = p.observe_full().cpu().numpy()
+    want = st.astype(np.float32) / np.float32(255.0)
+    assert got.dtype == np.float32 and np.array_equal(got.view(np.uint32), want.view(np.uint32))
+
+
+# ---------------------------------------------------------------- K1
+def _tie_pixels():
+    """RGB triples on exact .5 luminance ties (2989r+5870g+1140b = 5000 mod 10000)."""
+    out = []
+    for r in range(0, 256, 5):
+        for g in range(256):
+            for b in range(0, 256, 2):
+                if (2989 * r + 5870 * g + 1140 * b) % 10000 == 5000:
+                    out.append((r, g, b))
+    return np.array(out, dtype=np.uint8)
+
+
+def test_ingest_matches_oracle_sequence(dev):
+    N, fs = 7, 4
+    rng = np.random.default_rng(42)
+    p = _pipe(num_envs=N, kind="base", obs_size=(84, 84), frame_stack=fs)
+    ring = O.RingOracle(N, fs, (84, 84))
+    ties = _tie_pixels()
+    assert len(ties) > 50
+    for step in range(7):
+        frames = rng.integers(0, 256, (N, 2, 210, 160, 3), dtype=np.uint8)
+        # sprinkle luminance ties and extremes
+        idx = rng.integers(0, len(ties), size=(N, 2, 210, 160))
+        tie_mask = rng.random((N, 2, 210, 160)) < 0.02
+        frames[tie_mask] = ties[idx[tie_mask]]
+        frames[0, 0, :20] = 255
+        frames[0, 1, :20] = 0
+        nvalid = rng.integers(0, 3, N)
+        if step == 0:
+            nvalid[:] = 2
+        clear = (rng.random(N) < 0.2).astype(np.uint8)
+        skip = (rng.random(N) < 0.2).astype(np.uint8)
+        if step == 0:
+            skip[:] = 0
+        nvalid[clear == 1] = 1            # a reset appends one _get_state() frame
+        cmd = (nvalid | (clear * 0x04) | (skip * 0x08)).astype(np.uint8)
+        p.ingest(_t(frames, dev), _t(cmd, dev))
+        ring.ingest(frames, nvalid, clear=clear, skip=skip)
+        got = p.stack_u8().cpu().numpy()
+        assert np.array_equal(got, ring.stack_u8()), f"step {step}"
+    full = p.observe_full().cpu().numpy()
+    assert np.array_equal(full, O.u8_to_unit(ring.stack_u8()))
+
+
+def test_ingest_luminance_ties_exhaustive_rows(dev):
+    """Every tie triple, laid out as constant 2x2-source blocks, must come out as ALE's double rounding."""
+    ties = _tie_pixels()
+    N = 1
+    frames = np.zeros((N, 2, 210, 160, 3), np.uint8)
+    flat = frames[0, 0].reshape(-1, 3)
+    reps = np.repeat(ties, 1, axis=0)
+    flat[:] = reps[np.arange(flat.shape[0]) % len(reps)]
+    frames[0, 1] = frames[0, 0]
+    p = _pipe(num_envs=N, kind="base", obs_size=(84, 84), frame_stack=2)
+    p.ingest(_t(frames, dev), _t(np.array([2], np.uint8), dev))
+    got = p.stack_u8().cpu().numpy()[0, -1]
+    assert np.array_equal(got, O.get_state_u8(frames[0, 0], (84, 84)))
+
+
+@pytest.mark.parametrize("obs", [(84, 84), (64, 64), (96, 96), (40, 40)])
+def test_ingest_other_square_sizes(dev, obs):
+    N = 3
+    rng = np.random.default_rng(obs[0])
+    frames = rng.integers(0, 256, (N, 2, 210, 160, 3), dtype=np.uint8)
+    p = _pipe(num_envs=N, kind="base", obs_size=obs, frame_stack=2)
+    ring = O.RingOracle(N, 2, obs)
+    cmd = np.array([2, 1, 2], np.uint8)
+    p.ingest(_t(frames, dev), _t(cmd, dev))
+    ring.ingest(frames, cmd & 3)
+    assert np.array_equal(p.stack_u8().cpu().numpy(), ring.stack_u8())
+
+
+def test_ingest_rejects_non_square_and_bad_shapes(dev):
+    from active_gym import _native as nat
+    p = _pipe(num_envs=2, kind="base", obs_size=(36, 48), frame_stack=2)
+    frames = torch.zeros((2, 2, 210, 160, 3), dtype=torch.uint8, device=dev)
+    cmd = torch.full((2,), 2, dtype=torch.uint8, device=dev)
+    with pytest.raises(nat.AgxError, match="not square"):
+        p.ingest(frames, cmd)
+    with pytest.raises(ValueError):
+        p.ingest(frames[:1], cmd)
+    with pytest.raises(TypeError):
+        p.ingest(frames.float(), cmd)
+    with pytest.raises(ValueError):
+        _pipe(num_envs=2, kind="fixed", obs_size=(84, 84), fov_size=(84, 30))
+
+
+def test_ingest_gray_matches_oracle(dev):
+    N, fs, obs = 5, 3, (36, 48)
+    rng = np.random.default_rng(7)
+    p = _pipe(num_envs=N, kind="base", obs_size=obs, frame_stack=fs)
+    dq = [[np.zeros(obs, np.uint8)] * fs for _ in range(N)]
+    for step in range(5):
+        small = rng.integers(0, 256, (N, 2) + obs, dtype=np.uint8)
+        nvalid = rng.integers(0, 3, N)
+        clear = (rng.random(N) < 0.25).astype(np.uint8)
+        skip = (rng.random(N) < 0.25).astype(np.uint8)
+        cmd = (nvalid | clear * 4 | skip * 8).astype(np.uint8)
+        p.ingest_gray(_t(small, dev), _t(cmd, dev))
+        for i in range(N):
+            if skip[i]:
+                continue
+            if clear[i]:
+                dq[i] = [np.zeros(obs, np.uint8)] * fs
+            o = np.zeros(obs, np.uint8)
+            for f in range(nvalid[i]):
+                o = np.maximum(o, small[i, f])
+            dq[i] = dq[i][1:] + [o]
+        want = np.stack([np.stack(d) for d in dq])
+        assert np.array_equal(p.stack_u8().cpu().numpy(), want)
+
+
+# ---------------------------------------------------------------- golden replay (K2, K3, K4)
+def _pipe_for_case(c, n=1):
+    kind = {"fixed": "fixed", "flex": "flexible", "per": "peripheral"}[c["kind"]]
+    return _pipe(num_envs=n, kind=kind, obs_size=tuple(int(v) for v in c["obs_size"]),
+                 frame_stack=c["frame_stack"], fov_size=tuple(int(v) for v in c["fov_size"]),
+                 fov_init_loc=tuple(float(v) for v in c["init_loc"]), sensory_action_mode=c["mode"],
+                 sensory_action_space=tuple(float(v) for v in c["sas"]), resize_to_full=c["resize_to_full"],
+                 mask_out=c["mask_out"], peripheral_res=tuple(int(v) for v in c["peripheral_res"]),
+                 antialias=c["antialias"])
+
+
+def _compare(c, got, want, res=None):
+    """got: f32 [fs,h,w] from the device; want: golden (f32/f64, maybe ragged)."""
+    exact = c["kind"] != "per" and (c["mask_out"] or not c["resize_to_full"])
+    if c["kind"] == "flex" and not c["mask_out"] and not c["resize_to_full"]:
+        rh, rw = int(res[0]), int(res[1])
+        assert want.shape[-2:] == (rh, rw)
+        pad = got.copy()
+        pad[:, :rh, :rw] = 0
+        assert not pad.any(), "padding of the ragged raw window must be zero"
+        got = got[:, :rh, :rw]
+    assert got.shape == want.shape, (got.shape, want.shape)
+    np.testing.assert_allclose(got.astype(np.float64), want.astype(np.float64), rtol=0, atol=FLOAT_TOL)
+    return exact
+
+
+@pytest.mark.parametrize("name", fovea_case_names())
+def test_fovea_golden_replay(dev, name):
+    c = load_fovea(name)
+    p = _pipe_for_case(c)
+    flex = c["kind"] == "flex"
+    states = c["states_u8"]
+    p.set_stack_u8(_t(states[0][None], dev))
+    p.fovea_reset()
+    r = p.fovea()
+    res0 = r[2].cpu().numpy()[0] if flex else None
+    _compare(c, r[0].cpu().numpy()[0], c["outs"][0], res0)
+    assert np.array_equal(r[1].cpu().numpy()[0], c["fov_loc"][0])
+    worst = 0.0
+    for t in range(c["steps"]):
+        p.set_stack_u8(_t(states[t + 1][None], dev))
+        a = _t(c["actions"][t][None], dev)                     # float64, as the reference received it
+        if flex:
+            at = _t(np.array([c["action_types"][t]], np.int32), dev)
+            obs, loc, res = p.fovea(a, action_type=at)
+            assert np.array_equal(res.cpu().numpy()[0], c["fov_res"][t + 1]), t
+            rr = res.cpu().numpy()[0]
+        else:
+            obs, loc = p.fovea(a)
+            rr = None
+        assert np.array_equal(loc.cpu().numpy()[0], c["fov_loc"][t + 1]), (t, loc, c["fov_loc"][t + 1])
+        g = obs.cpu().numpy()[0]
+        w = c["outs"][t + 1]
+        exact = _compare(c, g, w, rr)
+        if exact and not (flex and int(rr[0]) > int(c["fov_size"][0])):
+            gg = g[:, :w.shape[-2], :w.shape[-1]] if g.shape != w.shape else g
+            assert np.array_equal(gg, w.astype(np.float32)), "crop / paste must be bit-exact"
+        worst = max(worst, float(np.abs(g[..., :w.shape[-2], :w.shape[-1]].astype(np.float64) - w).max()))
+    assert worst <= FLOAT_TOL
+
+
+# ---------------------------------------------------------------- batched vs oracle
+@pytest.mark.parametrize("mode", ["absolute", "relative"])
+@pytest.mark.parametrize("out", ["resize", "mask", "raw"])
+def test_fixed_batched_vs_oracle(dev, mode, out):
+    N, fs = 33, 4
+    rng = np.random.default_rng(hash((mode, out)) & 0xFFFF)
+    kw = dict(obs_size=(84, 84), fov_size=(30, 30), fov_init_loc=(27, 27), sensory_action_mode=mode,
+              sensory_action_space=(-10.0, 10.0), resize_to_full=(out == "resize"), mask_out=(out == "mask"))
+    p = _pipe(num_envs=N, kind="fixed", frame_stack=fs, **kw)
+    orcs = [O.FixedFovealOracle(**kw) for _ in range(N)]
+    for step in range(4):
+        st = rng.integers(0, 256, (N, fs, 84, 84), dtype=np.uint8)
+        p.set_stack_u8(_t(st, dev))
+        if mode == "absolute":
+            a = rng.uniform(-5, 60, (N, 2)).astype(np.float32)
+            a[::5] = np.floor(a[::5]) + 0.5
+        else:
+            a = rng.uniform(-14, 14, (N, 2)).astype(np.float32)
+            a[::4] = np.floor(a[::4]) + 0.5
+        a[1] = np.nan if step == 2 else a[1]
+        obs, loc = p.fovea(_t(a, dev))
+        obs, loc = obs.cpu().numpy(), loc.cpu().numpy()
+        for i in range(N):
+            ai = a[i]
+            if np.isnan(ai).any():
+                continue                       # NaN is normalised by the ABI; the reference is undefined
+            want = orcs[i].step(unit64(st[i]), ai)
+            assert np.array_equal(loc[i], orcs[i].fov_loc), (step, i, ai, loc[i], orcs[i].fov_loc)
+            if out == "resize":
+                np.testing.assert_allclose(obs[i], want, rtol=0, atol=FLOAT_TOL)
+            else:
+                assert np.array_equal(obs[i], want.astype(np.float32))
+        if step == 2:                          # resync the NaN env
+            orcs[1].fov_loc = loc[1].astype(np.int64)
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.float64, torch.int32, torch.int64])
+def test_action_dtypes_and_half_to_even(dev, dtype):
+    N = 8
+    p = _pipe(num_envs=N, kind="fixed", obs_size=(84, 84), fov_size=(30, 30), frame_stack=1, resize_to_full=False)
+    vals = np.array([[12.5, 13.5], [0.5, 1.5], [-3, 60.7], [53.5, 54.5], [54.49, 2.5], [7, 9], [100, -100], [22.5, 23.5]])
+    if dtype in (torch.int32, torch.int64):
+        vals = np.rint(vals)
+    a = torch.tensor(vals, dtype=dtype, device=dev)
+    _, loc = p.fovea(a)
+    want = np.rint(np.clip(a.cpu().numpy(), 0, 54)).astype(int)
+    assert np.array_equal(loc.cpu().numpy(), want)
+
+
+def test_mask_leaves_envs_untouched(dev):
+    N = 6
+    rng = np.random.default_rng(3)
+    p = _pipe(num_envs=N, kind="fixed", obs_size=(84, 84), fov_size=(30, 30), frame_stack=2, resize_to_full=True)
+    p.set_stack_u8(_t(rng.integers(0, 256, (N, 2, 84, 84), dtype=np.uint8), dev))
+    a = _t(rng.uniform(0, 54, (N, 2)).astype(np.float32), dev)
+    obs, loc = p.fovea(a)
+    obs0, loc0 = obs.clone(), loc.clone()
+    mask = _t(np.array([1, 0, 1, 0, 0, 1], np.uint8), dev)
+    a2 = _t(rng.uniform(0, 54, (N, 2)).astype(np.float32), dev)
+    sentinel = torch.full_like(obs, -7.0)
+    obs2, loc2 = p.fovea(a2, mask=mask, out=sentinel, loc_out=loc.clone())
+    m = mask.bool().cpu().numpy()
+    assert (obs2[~mask.bool()] == -7.0).all() and (obs2[mask.bool()] != -7.0).any()
+    st_loc, _ = p.fov_state()
+    assert np.array_equal(st_loc.cpu().numpy()[~m], loc0.cpu().numpy()[~m])
+    assert np.array_equal(loc2.cpu().numpy()[~m], loc0.cpu().numpy()[~m])
+    # reset only env 0
+    p.fovea_reset(_t(np.array([1, 0, 0, 0, 0, 0], np.uint8), dev))
+    st_loc2, _ = p.fov_state()
+    assert st_loc2[0].tolist() == [0, 0] and np.array_equal(st_loc2[1:].cpu().numpy(), st_loc.cpu().numpy()[1:])
+
+
+@pytest.mark.parametrize("aa", [False, True])
+def test_peripheral_batched_vs_oracle(dev, aa):
+    N, fs = 9, 4
+    rng = np.random.default_rng(11 + aa)
+    kw = dict(obs_size=(84, 84), fov_size=(30, 30), fov_init_loc=(0, 0), sensory_action_mode="absolute",
+              peripheral_res=(20, 20), antialias=aa)
+    p = _pipe(num_envs=N, kind="peripheral", frame_stack=fs, **kw)
+    orcs = [O.PeripheralOracle(**kw) for _ in range(N)]
+    for step in range(3):
+        st = rng.integers(0, 256, (N, fs, 84, 84), dtype=np.uint8)
+        p.set_stack_u8(_t(st, dev))
+        a = rng.uniform(-5, 60, (N, 2))
+        obs, loc = p.fovea(_t(a, dev))
+        obs, loc = obs.cpu().numpy(), loc.cpu().numpy()
+        for i in range(N):
+            want = orcs[i].step(unit64(st[i]), a[i])
+            assert np.array_equal(loc[i], orcs[i].fov_loc)
+            np.testing.assert_allclose(obs[i], want, rtol=0, atol=FLOAT_TOL)
+            r, c = loc[i]
+            assert np.array_equal(obs[i][:, r:r + 30, c:c + 30], want[:, r:r + 30, c:c + 30].astype(np.float32))
+
+
+@pytest.mark.parametrize("aa", [False, True])
+@pytest.mark.parametrize("out", ["resize", "mask", "raw"])
+def test_flexible_batched_vs_oracle(dev, aa, out):
+    N, fs = 17, 2
+    rng = np.random.default_rng(23 + aa + len(out))
+    kw = dict(obs_size=(84, 84), fov_size=(30, 30), fov_init_loc=(5, 6), sensory_action_mode="absolute",
+              resize_to_full=(out == "resize"), mask_out=(out == "mask"), antialias=aa)
+    p = _pipe(num_envs=N, kind="flexible", frame_stack=fs, **kw)
+    orcs = [O.FlexibleFovealOracle(**kw) for _ in range(N)]
+    for step in range(6):
+        st = rng.integers(0, 256, (N, fs, 84, 84), dtype=np.uint8)
+        p.set_stack_u8(_t(st, dev))
+        types = rng.integers(0, 2, N).astype(np.int32)
+        a = np.where(types[:, None] == 1, rng.integers(10, 61, (N, 2)), rng.integers(-5, 80, (N, 2))).astype(np.int64)
+        if step == 1:
+            types[0], a[0] = 1, (84, 84)
+            types[1], a[1] = 1, (31, 10)
+        obs, loc, res = p.fovea(_t(a, dev), action_type=_t(types, dev))
+        obs, loc, res = obs.cpu().numpy(), loc.cpu().numpy(), res.cpu().numpy()
+        for i in range(N):
+            want = orcs[i].step(unit64(st[i]), a[i], np.array((types[i],)))
+            assert np.array_equal(loc[i], orcs[i].fov_loc) and np.array_equal(res[i], orcs[i].fov_res)
+            got = obs[i]
+            if out == "raw":
+                rh, rw = res[i]
+                assert not got[:, rh:, :].any() and not got[:, :, rw:].any()
+                got = got[:, :rh, :rw]
+            np.testing.assert_allclose(got, want, rtol=0, atol=FLOAT_TOL)
+
+
+# ---------------------------------------------------------------- full benchmark size: properties
+def test_full_size_properties(dev):
+    """N=1024 (BASELINE.json configs[1]): size-independent checks instead of the slow oracle."""
+    N, fs = 1024, 4
+    g = torch.Generator(device="cpu").manual_seed(1234)
+    p = _pipe(num_envs=N, kind="fixed", obs_size=(84, 84), fov_size=(30, 30), frame_stack=fs, resize_to_full=True)
+    pm = _pipe(num_envs=N, kind="fixed", obs_size=(84, 84), fov_size=(30, 30), frame_stack=fs, mask_out=True)
+    pr = _pipe(num_envs=N, kind="fixed", obs_size=(84, 84), fov_size=(30, 30), frame_stack=fs)
+    # (1) constant-colour frames -> constant observation of that luminance, every env, every pixel
+    cols = torch.randint(0, 256, (N, 3), generator=g, dtype=torch.uint8)
+    frames = cols.view(N, 1, 1, 1, 3).expand(N, 2, 210, 160, 3).contiguous().to(dev)
+    cmd = torch.full((N,), 2, dtype=torch.uint8, device=dev)
+    lum = torch.from_numpy(O.ale_luminance(cols.numpy())).to(dev)
+    for q in (p, pm, pr):
+        for _ in range(fs):
+            q.ingest(frames, cmd)
+        st = q.stack_u8()
+        assert (st == lum.view(N, 1, 1, 1)).all()
+    a = (torch.rand((N, 2), generator=g) * 65 - 5).to(dev)
+    obs, loc = p.fovea(a)
+    want = (lum.float() / 255.0).view(N, 1, 1, 1)
+    assert (obs - want).abs().max().item() <= 2e-7          # interpolating a constant gives the constant
+    # (2) random frames: ingest twice with identical inputs == idempotent newest frame; max-pool commutes
+    fr = torch.randint(0, 256, (N, 2, 210, 160, 3), generator=g, dtype=torch.uint8).to(dev)
+    p.ingest(fr, cmd)
+    s1 = p.stack_u8()[:, -1].clone()
+    p.ingest(fr.flip(1).contiguous(), cmd)
+    s2 = p.stack_u8()
+    assert torch.equal(s2[:, -1], s1) and torch.equal(s2[:, -2], s1)
+    one = torch.full((N,), 1, dtype=torch.uint8, device=dev)
+    p.ingest(fr, one)
+    a0 = p.stack_u8()[:, -1].clone()
+    p.ingest(fr.flip(1).contiguous(), one)
+    a1 = p.stack_u8()[:, -1]
+    assert torch.equal(torch.maximum(a0, a1), s1)            # max of single-frame results == 2-frame result
+    # (3) the three output modes agree with each other on the window
+    for q in (pm, pr):
+        q.set_stack_u8(p.stack_u8())
+    obs_m, loc_m = pm.fovea(a)
+    obs_r, loc_r = pr.fovea(a)
+    obs_z, loc_z = p.fovea(a)
+    assert torch.equal(loc_m, loc_r) and torch.equal(loc_m, loc_z)
+    full = p.observe_full()
+    ar = torch.arange(30, device=dev)
+    rows = (loc_m[:, 0:1] + ar).long()
+    cols_ = (loc_m[:, 1:2] + ar).long()
+    win = full[torch.arange(N, device=dev)[:, None, None, None], torch.arange(fs, device=dev)[None, :, None, None],
+               rows[:, None, :, None], cols_[:, None, None, :]]
+    assert torch.equal(obs_r, win)
+    assert torch.equal(obs_m.sum((2, 3)), obs_m[torch.arange(N, device=dev)[:, None, None, None],
+                                                torch.arange(fs, device=dev)[None, :, None, None],
+                                                rows[:, None, :, None], cols_[:, None, None, :]].sum((2, 3)))
+    # resize output is a convex combination of the window: bounded by its min/max, corners exact
+    lo = win.amin((2, 3), keepdim=True)
+    hi = win.amax((2, 3), keepdim=True)
+    assert (obs_z >= lo - 1e-6).all() and (obs_z <= hi + 1e-6).all()
+    assert torch.allclose(obs_z[..., 0, 0], win[..., 0, 0], atol=1e-6) and \
+        torch.allclose(obs_z[..., -1, -1], win[..., -1, -1], atol=1e-6)
+    # (4) torch's own bilinear on the same window (float32 reference of the float kernel)
+    ref = torch.nn.functional.interpolate(win, size=(84, 84), mode="bilinear", align_corners=False)
+    assert (obs_z - ref).abs().max().item() <= FLOAT_TOL
