@@ -58,10 +58,41 @@ __device__ __forceinline__ float unit(uint32_t k) { return (float)k / 255.0f; }
 // The rational value (2989r+5870g+1140b)/10000 decides everything except exact .5 ties, where
 // the double evaluation sometimes lands below the tie (292 of 2^24 inputs); those are replayed
 // in double with the same operation order and no fused multiply-add.
-__device__ __forceinline__ uint32_t ale_lum(uint32_t r, uint32_t g, uint32_t b) {
+//
+// Instruction diet (K1 is issue-bound, not HBM-bound, unless this is tight):
+//   t   = 2989r + 5870g + 1140b + 5000 via two v_dot4_u32_u8 on the pixel dword
+//         (weights split as 256*(11,22,4) + (173,238,116)) and one v_lshl_add_u32;
+//   q   = floor(t / 10000) = v_mul_hi_u32_u24(t, ceil(2^37/1e4)) >> 5, exact for t < 2^22
+//         (t * eps / 2^37 < 1.9e-5 < the 1e-4 granularity of t/10000);
+//   tie = (q * 10000 == t), one v_mul_u32_u24 + v_cmp.
+constexpr uint32_t kLumWLo = 173u | (238u << 8) | (116u << 16);
+constexpr uint32_t kLumWHi = 11u | (22u << 8) | (4u << 16);
+
+__device__ __forceinline__ uint32_t ale_lum_px(uint32_t px /* r | g<<8 | b<<16 | any<<24 */, bool &tie) {
+    const uint32_t hi = __builtin_amdgcn_udot4(px, kLumWHi, 0u, false);
+    const uint32_t t = __builtin_amdgcn_udot4(px, kLumWLo, (hi << 8) + 5000u, false);
+    const uint32_t q = (uint32_t)(((uint64_t)(t & 0xFFFFFFu) * 13743896ull) >> 32) >> 5;
+    uint32_t back;                       // q * 10000 at full rate (hipcc otherwise picks v_mul_lo_u32)
+    asm("v_mul_u32_u24_e32 %0, %1, %2" : "=v"(back) : "v"(q), "v"(10000u));
+    tie |= back == t;
+    return q;
+}
+
+// 12 bytes = 4 RGB pixels -> 4 luminance bytes packed little-endian; `tie` is raised when any of
+// them sits on an exact .5 tie (the caller re-does that piece with ale_lum_exact)
+__device__ __forceinline__ uint32_t lum4(uint32_t a, uint32_t b, uint32_t c, bool &tie) {
+    const uint32_t q0 = ale_lum_px(a, tie);
+    const uint32_t q1 = ale_lum_px(__builtin_amdgcn_alignbyte(b, a, 3), tie);
+    const uint32_t q2 = ale_lum_px(__builtin_amdgcn_alignbyte(c, b, 2), tie);
+    const uint32_t q3 = ale_lum_px(c >> 8, tie);
+    return q0 | (q1 << 8) | (q2 << 16) | (q3 << 24);
+}
+
+// exact-tie replay of one pixel in C double, ALE's operation order, no fused multiply-add
+__device__ __forceinline__ uint32_t ale_lum_exact(uint32_t r, uint32_t g, uint32_t b) {
     const uint32_t t = 2989u * r + 5870u * g + 1140u * b + 5000u;
     uint32_t q = t / 10000u;
-    if (__builtin_expect(t - q * 10000u == 0u, 0)) {
+    if (t - q * 10000u == 0u) {
 #pragma clang fp contract(off)
         const double x = ((double)r * 0.2989 + (double)g * 0.5870) + (double)b * 0.1140;
         const double fl = floor(x);
@@ -79,12 +110,14 @@ struct IngestParams {
     const int2 *xtab;        // [ow]  {x0 | x1<<16, a0 | a1<<16}
     const int4 *ytab;        // [oh]  {y0, y1, b0, b1}
     int32_t oh, ow, fs;
-    int32_t band_rows;       // output rows per workgroup (band_rows * ow/4 <= 256)
+    int32_t band_rows;       // output rows per workgroup (band_rows * ow/4 <= 256, band_rows <= 12)
 };
 
 // grid = (bands, N), block = 256.  Per workgroup: the two source rows of each of its output rows,
 // for both frames, go HBM -> registers (12-byte / 4-pixel pieces, lane-contiguous) -> luminance ->
-// LDS as gray bytes; then each thread produces 4 adjacent output pixels and stores one dword.
+// LDS; then each thread produces 4 adjacent output pixels and stores one dword.
+// LDS gray layout: [frame][dyl][x][2] — the vertical pair (row y0, row y1) of one source column is
+// one aligned u16, so the bilinear taps of an output pixel are two ds_read_u16.
 __global__ __launch_bounds__(kThreads) void k_ingest(IngestParams p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int n = blockIdx.y;
@@ -104,71 +137,90 @@ __global__ __launch_bounds__(kThreads) void k_ingest(IngestParams p) {
     const int dy0 = band * BR;
     const int rows = min(BR, p.oh - dy0);
     int4 *ytab_s = reinterpret_cast<int4 *>(smem);                      // [BR]
-    unsigned char *gray = smem + sizeof(int4) * BR;                       // [2][BR][2][160]
+    unsigned char *gray = smem + sizeof(int4) * BR;                       // [2][BR][160][2]
     if (tid < rows) ytab_s[tid] = p.ytab[dy0 + tid];
+    // phase-2 coordinates and x taps, fetched now so that their latency hides under phase 1
+    const int ow4 = p.ow >> 2;
+    const bool p2 = tid < rows * ow4;
+    const int dyl2 = p2 ? tid / ow4 : 0, xq = p2 ? tid - dyl2 * ow4 : 0;
+    const int4 xt01 = *reinterpret_cast<const int4 *>(p.xtab + xq * 4);
+    const int4 xt23 = *reinterpret_cast<const int4 *>(p.xtab + xq * 4 + 2);
     __syncthreads();
 
-    // phase 1: RGB rows -> gray bytes in LDS
+    // phase 1: thread = (piece g4 of 40, row group rg of 6); row job rj = rg + 6k is (frame, output
+    // row); it loads both source rows of that output row, 4 pixels wide -> 8 gray bytes in LDS.
+    // Loads are unconditional (row job clamped) so that all of a thread's loads are in flight before
+    // the first use; only the LDS store is predicated.
     constexpr int G4 = kRawW / 4;                                         // 40 four-pixel pieces per row
-    const int ntask = nvalid * rows * 2 * G4;
-    const uint8_t *fbase = p.frames + (size_t)n * 2 * kRawFrameBytes;
-    constexpr int kIter = 8;                                              // 2*12*2*40 / 256 = 7.5
-    for (int base = 0; base < ntask; base += kIter * kThreads) {
-        uint32_t w[kIter][3];
+    constexpr int RG = kThreads / G4;                                     // 6 row groups (240 threads)
+    constexpr int kIter = 4;                                              // 2 frames * 12 rows / 6
+    const int nrj = nvalid * rows;                                        // <= 24
+    struct __attribute__((aligned(4))) U3 { uint32_t x, y, z; };
+    if (nrj > 0) {
+        const int rg = tid / G4, g4 = tid - rg * G4;
+        const uint8_t *fbase = p.frames + (size_t)n * 2 * kRawFrameBytes;   // wave-uniform base
+        const uint32_t col = g4 * 12;
+        U3 w0[kIter], w1[kIter];
         int dst[kIter];
 #pragma unroll
         for (int it = 0; it < kIter; ++it) {
-            const int task = base + it * kThreads + tid;
-            dst[it] = -1;
-            if (task < ntask) {
-                const int rj = task / G4, g4 = task - rj * G4;            // row job = (f, dyl, which)
-                const int f = rj >= 2 * rows ? 1 : 0;                     // nvalid <= 2
-                const int rr = rj - f * 2 * rows;
-                const int dyl = rr >> 1, which = rr & 1;
-                const int4 yt = ytab_s[dyl];
-                const int row = which ? yt.y : yt.x;
-                const uint32_t *src = reinterpret_cast<const uint32_t *>(
-                    fbase + (size_t)f * kRawFrameBytes + (size_t)row * kRawRowBytes + g4 * 12);
-                w[it][0] = src[0];
-                w[it][1] = src[1];
-                w[it][2] = src[2];
-                dst[it] = ((f * BR + dyl) * 2 + which) * kRawW + g4 * 4;
-            }
+            const int rj_raw = rg + RG * it;
+            const int rj = min(rj_raw, nrj - 1);
+            const int f = rj >= rows ? 1 : 0;                             // nvalid <= 2
+            const int dyl = rj - f * rows;
+            const int4 yt = ytab_s[dyl];
+            const uint32_t fo = f * kRawFrameBytes + col;                 // 32-bit lane offsets
+            w0[it] = *reinterpret_cast<const U3 *>(fbase + (fo + __umul24((uint32_t)yt.x, kRawRowBytes)));
+            w1[it] = *reinterpret_cast<const U3 *>(fbase + (fo + __umul24((uint32_t)yt.y, kRawRowBytes)));
+            dst[it] = (rj_raw < nrj && rg < RG) ? ((f * BR + dyl) * kRawW + g4 * 4) * 2 : -1;
         }
 #pragma unroll
         for (int it = 0; it < kIter; ++it) {
+            bool tie = false;
+            const uint32_t top = lum4(w0[it].x, w0[it].y, w0[it].z, tie);
+            const uint32_t bot = lum4(w1[it].x, w1[it].y, w1[it].z, tie);
             if (dst[it] >= 0) {
-                const uint32_t a = w[it][0], b = w[it][1], c = w[it][2];
-                const uint32_t g0 = ale_lum(a & 0xFF, (a >> 8) & 0xFF, (a >> 16) & 0xFF);
-                const uint32_t g1 = ale_lum(a >> 24, b & 0xFF, (b >> 8) & 0xFF);
-                const uint32_t g2 = ale_lum((b >> 16) & 0xFF, b >> 24, c & 0xFF);
-                const uint32_t g3 = ale_lum((c >> 8) & 0xFF, (c >> 16) & 0xFF, c >> 24);
-                *reinterpret_cast<uint32_t *>(gray + dst[it]) = g0 | (g1 << 8) | (g2 << 16) | (g3 << 24);
+                uint2 v;                                                  // t0 b0 t1 b1 | t2 b2 t3 b3
+                v.x = __builtin_amdgcn_perm(bot, top, 0x05010400u);
+                v.y = __builtin_amdgcn_perm(bot, top, 0x07030602u);
+                *reinterpret_cast<uint2 *>(gray + dst[it]) = v;
+                if (__builtin_expect(tie, 0)) {
+                    // about 1e-4 of random pixels: redo this piece pixel by pixel with the exact rule
+                    const uint32_t ww[2][3] = {{w0[it].x, w0[it].y, w0[it].z}, {w1[it].x, w1[it].y, w1[it].z}};
+#pragma nounroll
+                    for (int j = 0; j < 8; ++j) {
+                        const int which = j & 1, k = j >> 1;
+                        const uint64_t lo = (uint64_t)ww[which][0] | ((uint64_t)ww[which][1] << 32);
+                        const uint64_t hi = (uint64_t)ww[which][1] | ((uint64_t)ww[which][2] << 32);
+                        const uint32_t px = (uint32_t)(k < 2 ? (lo >> (24 * k)) : (hi >> (24 * k - 32)));
+                        gray[dst[it] + j] = (unsigned char)ale_lum_exact(px & 0xFF, (px >> 8) & 0xFF, (px >> 16) & 0xFF);
+                    }
+                }
             }
         }
     }
     __syncthreads();
 
     // phase 2: OpenCV fixed-point bilinear + max over the sampled frames
-    const int ow4 = p.ow >> 2;
-    if (tid < rows * ow4) {
-        const int dyl = tid / ow4, xq = tid - dyl * ow4;
+    if (p2) {
+        const int dyl = dyl2;
         const int dy = dy0 + dyl;
         const int4 yt = ytab_s[dyl];
         const int b0 = yt.z, b1 = yt.w;
         uint32_t packed = 0;
+        const int xi[4] = {xt01.x, xt01.z, xt23.x, xt23.z};
+        const int xa[4] = {xt01.y, xt01.w, xt23.y, xt23.w};
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
-            const int2 xt = p.xtab[xq * 4 + k];
-            const int x0 = xt.x & 0xFFFF, x1 = xt.x >> 16;
-            const int a0 = xt.y & 0xFFFF, a1 = xt.y >> 16;
+            const int x0 = xi[k] & 0xFFFF, x1 = xi[k] >> 16;
+            const int a0 = xa[k] & 0xFFFF, a1 = xa[k] >> 16;
             int best = 0;
             for (int f = 0; f < nvalid; ++f) {
-                const unsigned char *r0 = gray + ((f * BR + dyl) * 2) * kRawW;
-                const unsigned char *r1 = r0 + kRawW;
-                const int h0 = (int)r0[x0] * a0 + (int)r0[x1] * a1;
-                const int h1 = (int)r1[x0] * a0 + (int)r1[x1] * a1;
-                const int v = ((((b0 * (h0 >> 4)) >> 16) + ((b1 * (h1 >> 4)) >> 16) + 2) >> 2) & 0xFF;
+                const uint16_t *row = reinterpret_cast<const uint16_t *>(gray + (size_t)(f * BR + dyl) * kRawW * 2);
+                const uint32_t p0 = row[x0], p1 = row[x1];               // lo byte: row y0, hi byte: row y1
+                const int h0 = __mul24((int)(p0 & 0xFF), a0) + __mul24((int)(p1 & 0xFF), a1);
+                const int h1 = __mul24((int)(p0 >> 8), a0) + __mul24((int)(p1 >> 8), a1);
+                const int v = (((__mul24(b0, h0 >> 4) >> 16) + (__mul24(b1, h1 >> 4) >> 16) + 2) >> 2) & 0xFF;
                 best = max(best, v);
             }
             packed |= (uint32_t)best << (8 * k);

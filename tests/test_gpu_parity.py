@@ -396,9 +396,10 @@ def test_full_size_properties(dev):
     win = full[torch.arange(N, device=dev)[:, None, None, None], torch.arange(fs, device=dev)[None, :, None, None],
                rows[:, None, :, None], cols_[:, None, None, :]]
     assert torch.equal(obs_r, win)
-    assert torch.equal(obs_m.sum((2, 3)), obs_m[torch.arange(N, device=dev)[:, None, None, None],
-                                                torch.arange(fs, device=dev)[None, :, None, None],
-                                                rows[:, None, :, None], cols_[:, None, None, :]].sum((2, 3)))
+    expect_m = torch.zeros_like(obs_m)
+    expect_m[torch.arange(N, device=dev)[:, None, None, None], torch.arange(fs, device=dev)[None, :, None, None],
+             rows[:, None, :, None], cols_[:, None, None, :]] = win
+    assert torch.equal(obs_m, expect_m)
     # resize output is a convex combination of the window: bounded by its min/max, corners exact
     lo = win.amin((2, 3), keepdim=True)
     hi = win.amax((2, 3), keepdim=True)
