@@ -5,6 +5,7 @@
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <new>
 #include <set>
@@ -29,7 +30,9 @@ struct agx_ctx {
     Tap *fx_xtab = nullptr;    // K2 tables
     Tap *fx_ytab = nullptr;
     int band_rows = 0;
+    int ingest_t = 256;
     int rows_touched = 0;
+    int y_affine = 0, y_mul = 0, y_add = 0, y_shift = 0;   // see IngestParams
     int init_r = 0, init_c = 0;
     std::string err;
 };
@@ -109,8 +112,11 @@ int upload(agx_ctx *ctx, T **dptr, const std::vector<T> &h) {
 bool has_fovea(const agx_config &c) { return c.kind != AGX_KIND_BASE; }
 
 size_t fixed_lds(const agx_config &c) {
-    const size_t s = ((size_t)c.fov_h * c.fov_w + 3) & ~(size_t)3;
-    return (s + (c.out_mode == AGX_OUT_RESIZE ? (size_t)c.fov_h * c.obs_w : 0)) * sizeof(float);
+    // lut[256] f32 | raw frame u8 (16-B padded) | ytab[oh] | H[fh][ow]
+    const size_t raw = ((size_t)c.obs_h * c.obs_w + 15) & ~(size_t)15;
+    size_t b = 1024 + raw;
+    if (c.out_mode == AGX_OUT_RESIZE) b += (size_t)c.obs_h * sizeof(Tap) + (size_t)c.fov_h * c.obs_w * sizeof(float);
+    return b;
 }
 
 // second LDS buffer of the generic kernels, in floats: flexible ping-pongs two full frames,
@@ -228,10 +234,33 @@ int agx_create(const agx_config *cfg, agx_ctx **out) {
             touched.insert(y1[i]);
         }
         ctx->rows_touched = (int)touched.size();
+        // look for an exact integer form of the row table: y0 = (dy*mul + add) >> shift, y1 = min(y0+1, H-1)
+        for (int sh = 0; sh <= 12 && !ctx->y_affine; ++sh) {
+            const long mul = std::lround((double)kRawH / c.obs_h * (double)(1 << sh));
+            for (long add = -(1L << sh); add <= (1L << (sh + 1)) && !ctx->y_affine; ++add) {
+                bool ok = true;
+                for (int i = 0; i < c.obs_h && ok; ++i) {
+                    const long v = (i * mul + add) >> sh;
+                    ok = v >= 0 && v == y0[i] && std::min<long>(v + 1, kRawH - 1) == y1[i];
+                }
+                if (ok) {
+                    ctx->y_affine = 1;
+                    ctx->y_mul = (int)mul;
+                    ctx->y_add = (int)add;
+                    ctx->y_shift = sh;
+                }
+            }
+        }
         if ((rc = upload(ctx, &ctx->in_xtab, xt)) != AGX_OK) return bail(rc);
         if ((rc = upload(ctx, &ctx->in_ytab, yt)) != AGX_OK) return bail(rc);
+        // ingest workgroup: T threads produce band_rows output rows (band_rows * ow/4 <= T and the
+        // 2 * band_rows row jobs fit the T/40 loader groups x 4 iterations).  128-thread workgroups give
+        // 16 independent workgroups per CU whose load / compute phases interleave (AGX_INGEST_T tunes).
         const int ow4 = c.obs_w / 4;
-        ctx->band_rows = std::max(1, std::min(12, kThreads / ow4));
+        static const int forced_t = [] { const char *e = getenv("AGX_INGEST_T"); return e ? atoi(e) : 0; }();
+        ctx->ingest_t = (forced_t == 128 || forced_t == 256) ? forced_t : 256;   // 8 WGs/CU whatever T: 256 fills the wave slots
+        if (ow4 > 128) ctx->ingest_t = 256;
+        ctx->band_rows = std::max(1, std::min(2 * (ctx->ingest_t / 40), ctx->ingest_t / ow4));
     }
     if (has_fovea(c)) {
         // _init_fov_loc: np.rint(fov_init_loc).astype(np.int32)  (not clipped)   fov_env.py:149-150
@@ -320,9 +349,16 @@ int agx_ingest(agx_ctx *ctx, const uint8_t *d_frames, const uint8_t *d_cmd, void
     p.ow = c.obs_w;
     p.fs = c.frame_stack;
     p.band_rows = ctx->band_rows;
+    p.y_affine = ctx->y_affine;
+    p.y_mul = ctx->y_mul;
+    p.y_add = ctx->y_add;
+    p.y_shift = ctx->y_shift;
     const int bands = (c.obs_h + ctx->band_rows - 1) / ctx->band_rows;
-    const size_t lds = sizeof(int4) * ctx->band_rows + (size_t)2 * ctx->band_rows * 2 * kRawW;
-    hipLaunchKernelGGL(k_ingest, dim3(bands, c.num_envs), dim3(kThreads), lds, S(stream), p);
+    const size_t lds = sizeof(int4) * ctx->band_rows + sizeof(int2) * c.obs_w + (size_t)2 * ctx->band_rows * 2 * kRawW;
+    if (ctx->ingest_t == 128)
+        hipLaunchKernelGGL(k_ingest<128>, dim3(bands, c.num_envs), dim3(128), lds, S(stream), p);
+    else
+        hipLaunchKernelGGL(k_ingest<256>, dim3(bands, c.num_envs), dim3(256), lds, S(stream), p);
     AGX_HIP(ctx, hipGetLastError());
     ctx->cur_head ^= 1;
     return AGX_OK;
@@ -478,11 +514,11 @@ int agx_fovea_fixed(agx_ctx *ctx, const void *d_action, int action_dtype, const 
     if (rc) return rc;
     DeviceGuard g(c.device);
     const FovParams p = fov_params(ctx, d_action, action_dtype, nullptr, d_mask, d_obs, d_fov_loc, nullptr);
-    const dim3 grid(c.frame_stack, c.num_envs), block(kThreads);
     const size_t lds = fixed_lds(c);
     const bool headline = c.obs_h == 84 && c.obs_w == 84 && c.fov_h == 30 && c.fov_w == 30;
     using GS = GeomS<84, 84, 30, 30>;
     const GeomR gr{c.obs_h, c.obs_w, c.fov_h, c.fov_w};
+    const dim3 grid(c.frame_stack, c.num_envs), block(kThreads);
 #define LAUNCH(MODE)                                                                                  \
     do {                                                                                              \
         if (headline)                                                                                 \

@@ -111,14 +111,19 @@ struct IngestParams {
     const int4 *ytab;        // [oh]  {y0, y1, b0, b1}
     int32_t oh, ow, fs;
     int32_t band_rows;       // output rows per workgroup (band_rows * ow/4 <= 256, band_rows <= 12)
+    // y0(dy) == (dy * y_mul + y_add) >> y_shift and y1 == min(y0 + 1, raw_h - 1) for every dy (checked
+    // exhaustively against ytab at agx_create); lets the frame loads start without a table round trip.
+    int32_t y_affine, y_mul, y_add, y_shift;
 };
 
-// grid = (bands, N), block = 256.  Per workgroup: the two source rows of each of its output rows,
-// for both frames, go HBM -> registers (12-byte / 4-pixel pieces, lane-contiguous) -> luminance ->
-// LDS; then each thread produces 4 adjacent output pixels and stores one dword.
+// grid = (bands, N), block = T threads (T = 128 or 256).  Per workgroup: the two source rows of each
+// of its output rows, for both frames, go HBM -> registers (12-byte / 4-pixel pieces, lane-contiguous)
+// -> luminance -> LDS; then each thread produces 4 adjacent output pixels and stores one dword.
 // LDS gray layout: [frame][dyl][x][2] — the vertical pair (row y0, row y1) of one source column is
 // one aligned u16, so the bilinear taps of an output pixel are two ds_read_u16.
-__global__ __launch_bounds__(kThreads) void k_ingest(IngestParams p) {
+// Measured floor of this access shape with no arithmetic at all: ~30 us at N=1024 (tools/membench.hip).
+template <int T>
+__global__ __launch_bounds__(T) void k_ingest(IngestParams p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int n = blockIdx.y;
     const int band = blockIdx.x;
@@ -137,43 +142,60 @@ __global__ __launch_bounds__(kThreads) void k_ingest(IngestParams p) {
     const int dy0 = band * BR;
     const int rows = min(BR, p.oh - dy0);
     int4 *ytab_s = reinterpret_cast<int4 *>(smem);                      // [BR]
-    unsigned char *gray = smem + sizeof(int4) * BR;                       // [2][BR][160][2]
-    if (tid < rows) ytab_s[tid] = p.ytab[dy0 + tid];
-    // phase-2 coordinates and x taps, fetched now so that their latency hides under phase 1
+    int2 *xtab_s = reinterpret_cast<int2 *>(smem + sizeof(int4) * BR);    // [ow]
+    unsigned char *gray = smem + sizeof(int4) * BR + sizeof(int2) * p.ow; // [2][BR][160][2]
     const int ow4 = p.ow >> 2;
-    const bool p2 = tid < rows * ow4;
-    const int dyl2 = p2 ? tid / ow4 : 0, xq = p2 ? tid - dyl2 * ow4 : 0;
-    const int4 xt01 = *reinterpret_cast<const int4 *>(p.xtab + xq * 4);
-    const int4 xt23 = *reinterpret_cast<const int4 *>(p.xtab + xq * 4 + 2);
-    __syncthreads();
+    if (!p.y_affine) {                       // general geometry: source rows come from the table
+        if (tid < rows) ytab_s[tid] = p.ytab[dy0 + tid];
+        __syncthreads();
+    }
 
-    // phase 1: thread = (piece g4 of 40, row group rg of 6); row job rj = rg + 6k is (frame, output
-    // row); it loads both source rows of that output row, 4 pixels wide -> 8 gray bytes in LDS.
+    // phase 1: thread = (piece g4 of 40, row group rg of T/40); row job rj = rg + RG*it is (frame,
+    // output row); it loads both source rows of that output row, 4 pixels wide -> 8 gray bytes in LDS.
     // Loads are unconditional (row job clamped) so that all of a thread's loads are in flight before
     // the first use; only the LDS store is predicated.
     constexpr int G4 = kRawW / 4;                                         // 40 four-pixel pieces per row
-    constexpr int RG = kThreads / G4;                                     // 6 row groups (240 threads)
-    constexpr int kIter = 4;                                              // 2 frames * 12 rows / 6
-    const int nrj = nvalid * rows;                                        // <= 24
+    constexpr int RG = T / G4;                                            // row groups: 6 (T=256) / 3 (T=128)
+    constexpr int kIter = 4;                                              // 2 frames * band_rows / RG
+    const int nrj = nvalid * rows;                                        // <= RG * kIter
     struct __attribute__((aligned(4))) U3 { uint32_t x, y, z; };
     if (nrj > 0) {
         const int rg = tid / G4, g4 = tid - rg * G4;
         const uint8_t *fbase = p.frames + (size_t)n * 2 * kRawFrameBytes;   // wave-uniform base
         const uint32_t col = g4 * 12;
-        U3 w0[kIter], w1[kIter];
-        int dst[kIter];
-#pragma unroll
-        for (int it = 0; it < kIter; ++it) {
+        auto row_offsets = [&](int it, uint32_t &o0, uint32_t &o1, int &d) {
             const int rj_raw = rg + RG * it;
             const int rj = min(rj_raw, nrj - 1);
             const int f = rj >= rows ? 1 : 0;                             // nvalid <= 2
             const int dyl = rj - f * rows;
-            const int4 yt = ytab_s[dyl];
+            int y0, y1;
+            if (p.y_affine) {
+                y0 = ((dy0 + dyl) * p.y_mul + p.y_add) >> p.y_shift;
+                y1 = min(y0 + 1, kRawH - 1);
+            } else {
+                const int4 yt = ytab_s[dyl];
+                y0 = yt.x;
+                y1 = yt.y;
+            }
             const uint32_t fo = f * kRawFrameBytes + col;                 // 32-bit lane offsets
-            w0[it] = *reinterpret_cast<const U3 *>(fbase + (fo + __umul24((uint32_t)yt.x, kRawRowBytes)));
-            w1[it] = *reinterpret_cast<const U3 *>(fbase + (fo + __umul24((uint32_t)yt.y, kRawRowBytes)));
-            dst[it] = (rj_raw < nrj && rg < RG) ? ((f * BR + dyl) * kRawW + g4 * 4) * 2 : -1;
+            o0 = fo + __umul24((uint32_t)y0, kRawRowBytes);
+            o1 = fo + __umul24((uint32_t)y1, kRawRowBytes);
+            d = (rj_raw < nrj && rg < RG) ? ((f * BR + dyl) * kRawW + g4 * 4) * 2 : -1;
+        };
+        U3 w0[kIter], w1[kIter];
+        int dst[kIter];
+#pragma unroll
+        for (int it = 0; it < kIter; ++it) {
+            uint32_t o0, o1;
+            row_offsets(it, o0, o1, dst[it]);
+            w0[it] = *reinterpret_cast<const U3 *>(fbase + o0);
+            w1[it] = *reinterpret_cast<const U3 *>(fbase + o1);
         }
+        // the phase-2 tables are requested AFTER the frame pieces (vmcnt retires in order, so waiting
+        // for them later costs nothing) and parked in LDS once the luminance work is done
+        const int4 yt_own = p.ytab[dy0 + min(tid, rows - 1)];
+        const int2 xt_own = p.xtab[min(tid, p.ow - 1)];
+        uint32_t tie_its = 0;
 #pragma unroll
         for (int it = 0; it < kIter; ++it) {
             bool tie = false;
@@ -184,29 +206,54 @@ __global__ __launch_bounds__(kThreads) void k_ingest(IngestParams p) {
                 v.x = __builtin_amdgcn_perm(bot, top, 0x05010400u);
                 v.y = __builtin_amdgcn_perm(bot, top, 0x07030602u);
                 *reinterpret_cast<uint2 *>(gray + dst[it]) = v;
-                if (__builtin_expect(tie, 0)) {
-                    // about 1e-4 of random pixels: redo this piece pixel by pixel with the exact rule
-                    const uint32_t ww[2][3] = {{w0[it].x, w0[it].y, w0[it].z}, {w1[it].x, w1[it].y, w1[it].z}};
+                tie_its |= tie ? (1u << it) : 0u;
+            }
+        }
+#ifndef AGX_K1_NOTIE
+        if (__builtin_expect(tie_its != 0, 0)) {
+            // about 1e-4 of random pixels sit on an exact .5 tie: redo those pieces byte by byte with
+            // the exact rule.  The source bytes are re-read (L2 hits) so that the fast path does not
+            // have to keep 24 registers alive for this branch.
 #pragma nounroll
-                    for (int j = 0; j < 8; ++j) {
-                        const int which = j & 1, k = j >> 1;
-                        const uint64_t lo = (uint64_t)ww[which][0] | ((uint64_t)ww[which][1] << 32);
-                        const uint64_t hi = (uint64_t)ww[which][1] | ((uint64_t)ww[which][2] << 32);
-                        const uint32_t px = (uint32_t)(k < 2 ? (lo >> (24 * k)) : (hi >> (24 * k - 32)));
-                        gray[dst[it] + j] = (unsigned char)ale_lum_exact(px & 0xFF, (px >> 8) & 0xFF, (px >> 16) & 0xFF);
-                    }
+            for (int it = 0; it < kIter; ++it) {
+                if (!((tie_its >> it) & 1u)) continue;
+                uint32_t o0, o1;
+                int d;
+                row_offsets(it, o0, o1, d);
+                const U3 a = *reinterpret_cast<const U3 *>(fbase + o0);   // one round trip, then registers only
+                const U3 b = *reinterpret_cast<const U3 *>(fbase + o1);
+#pragma nounroll
+                for (int j = 0; j < 8; ++j) {
+                    const bool which = j & 1;
+                    const int k = j >> 1;
+                    const uint32_t x = which ? b.x : a.x, y = which ? b.y : a.y, z = which ? b.z : a.z;
+                    const uint64_t lo = (uint64_t)x | ((uint64_t)y << 32);
+                    const uint64_t hi = (uint64_t)y | ((uint64_t)z << 32);
+                    const uint32_t px = (uint32_t)(k < 2 ? (lo >> (24 * k)) : (hi >> (24 * k - 32)));
+                    gray[d + j] = (unsigned char)ale_lum_exact(px & 0xFF, (px >> 8) & 0xFF, (px >> 16) & 0xFF);
                 }
             }
         }
+#endif
+        if (tid < rows) ytab_s[tid] = yt_own;
+        if (tid < p.ow) xtab_s[tid] = xt_own;
+        for (int i = tid + T; i < p.ow; i += T) xtab_s[i] = p.xtab[i];
     }
     __syncthreads();
 
     // phase 2: OpenCV fixed-point bilinear + max over the sampled frames
-    if (p2) {
-        const int dyl = dyl2;
+    if (tid < rows * ow4) {
+        const int dyl = tid / ow4, xq = tid - dyl * ow4;
         const int dy = dy0 + dyl;
-        const int4 yt = ytab_s[dyl];
-        const int b0 = yt.z, b1 = yt.w;
+        int b0 = 0, b1 = 0;
+        int4 xt01 = make_int4(0, 0, 0, 0), xt23 = xt01;
+        if (nvalid) {
+            const int4 yt = ytab_s[dyl];
+            b0 = yt.z;
+            b1 = yt.w;
+            xt01 = *reinterpret_cast<const int4 *>(xtab_s + xq * 4);
+            xt23 = *reinterpret_cast<const int4 *>(xtab_s + xq * 4 + 2);
+        }
         uint32_t packed = 0;
         const int xi[4] = {xt01.x, xt01.z, xt23.x, xt23.z};
         const int xa[4] = {xt01.y, xt01.w, xt23.y, xt23.w};
@@ -366,12 +413,47 @@ struct FovParams {
     int32_t buf1_floats;        // generic kernels: size of the second LDS buffer (multiple of 4)
 };
 
-__device__ __forceinline__ void next_loc(const FovParams &p, int n, int bound_r, int bound_c, int &r, int &c) {
-    r = p.loc_in[2 * n];
-    c = p.loc_in[2 * n + 1];
+// Raw inputs of the fov_loc update.  Kept separate from the arithmetic so that a kernel can issue
+// these (vector) loads BEFORE its bulk loads: vmcnt retires in order, so waiting for them later does
+// not drain the younger bulk loads.
+struct LocIn {
+    int r, c;
+    uint32_t w[4];       // raw bits of the two action elements (4- or 8-byte each), converted later
+};
+__device__ __forceinline__ LocIn load_loc_inputs(const FovParams &p, int n) {
+    LocIn in;
+    const int2 rc = *reinterpret_cast<const int2 *>(p.loc_in + 2 * n);
+    in.r = rc.x;
+    in.c = rc.y;
+    // two unconditional 8-byte loads, no branch and no use of the bits here, so no wait is forced:
+    // 4-byte elements: a0 holds both; 8-byte elements: a0, a1 hold one each.  A null action reads
+    // loc_in instead (ignored later).
+    const bool wide = p.action_dt == AGX_DT_F64 || p.action_dt == AGX_DT_I64;
+    const char *base = p.action ? static_cast<const char *>(p.action) + (size_t)n * (wide ? 16 : 8)
+                                : reinterpret_cast<const char *>(p.loc_in + 2 * n);
+    const uint2 a0 = *reinterpret_cast<const uint2 *>(base);
+    const uint2 a1 = *reinterpret_cast<const uint2 *>(base + ((wide && p.action) ? 8 : 0));
+    in.w[0] = a0.x;
+    in.w[1] = wide ? a0.y : 0u;
+    in.w[2] = wide ? a1.x : a0.y;
+    in.w[3] = wide ? a1.y : 0u;
+    return in;
+}
+__device__ __forceinline__ double action_value(int dt, uint32_t lo, uint32_t hi) {
+    switch (dt) {
+        case AGX_DT_F32: return (double)__uint_as_float(lo);
+        case AGX_DT_F64: return __longlong_as_double((long long)(((uint64_t)hi << 32) | lo));
+        case AGX_DT_I32: return (double)(int32_t)lo;
+        default: return (double)(int64_t)(((uint64_t)hi << 32) | lo);
+    }
+}
+__device__ __forceinline__ void compute_loc(const FovParams &p, const LocIn &in, int bound_r, int bound_c, int &r,
+                                            int &c) {
+    r = in.r;
+    c = in.c;
     if (p.action) {
-        const double ar = load_action(p.action, p.action_dt, 2 * (size_t)n);
-        const double ac = load_action(p.action, p.action_dt, 2 * (size_t)n + 1);
+        const double ar = action_value(p.action_dt, in.w[0], in.w[1]);
+        const double ac = action_value(p.action_dt, in.w[2], in.w[3]);
         if (p.relative) {
             const int dr = clip_rint(ar, p.sas_lo, p.sas_hi);
             const int dc = clip_rint(ac, p.sas_lo, p.sas_hi);
@@ -382,6 +464,10 @@ __device__ __forceinline__ void next_loc(const FovParams &p, int n, int bound_r,
             c = clip_rint(ac, 0.0, (double)bound_c);
         }
     }
+}
+__device__ __forceinline__ void next_loc(const FovParams &p, int n, int bound_r, int bound_c, int &r, int &c) {
+    const LocIn in = load_loc_inputs(p, n);
+    compute_loc(p, in, bound_r, bound_c, r, c);
 }
 
 // Stage the window [r, r+h) x [c, c+w) of one u8 frame (row pitch ow, ow % 4 == 0) into LDS as
@@ -409,18 +495,70 @@ __device__ __forceinline__ void stage_window(const uint8_t *frame, int ow, int r
 //   MODE = AGX_OUT_RESIZE: LDS s[fh][fw] -> H[fh][ow] (horizontal lerp) -> float4 rows of the
 //          84x84 output = vertical lerp of two ds_read_b128; every store is 16 B/lane, lane-linear.
 // ---------------------------------------------------------------------------------------------
+template <class T4>
+__device__ __forceinline__ void store_obs(T4 *dst, const T4 &v) {
+#ifndef AGX_K2_PLAIN_STORES
+    // write-once stream: nontemporal, so the next launch (K1) does not queue behind ~115 MB of dirty
+    // L2 / Infinity-Cache lines (measured: K1 is ~6 us faster after nontemporal obs stores)
+    typedef float f4v __attribute__((ext_vector_type(4)));
+    const f4v w = {v.x, v.y, v.z, v.w};
+    __builtin_nontemporal_store(w, reinterpret_cast<f4v *>(dst));
+#else
+    *dst = v;
+#endif
+}
+
+// grid = (fs, N): workgroup (sl, n) owns PHYSICAL ring slot sl of env n, block = 256.
+// Every stage that costs a memory round trip is started at once:
+//   * the whole u8 frame of that slot (address known at launch) -> registers -> LDS,
+//   * the scalar chain action / fov_loc / head -> (r, c) and the stack position j of this slot,
+//   * this thread's column taps (registers) and one row-tap entry (-> LDS).
+// u8 -> float32 k/255 goes through a 256-entry LDS table (one exact division per thread).
+//   RESIZE: H[fh][ow] = horizontal lerp of the window rows (thread = fixed column x, rows y = yb+3k),
+//           then each output float4 is the vertical lerp of two ds_read_b128; stores are 16 B per
+//           lane, lane-linear, 1 KiB per wave at 1-KiB steps, nontemporal.
+// (ablation of the previous serial version at N=1024: loc chain 5.8 us, loc-dependent window load
+//  6.3 us, H pass with a tap load per iteration 7.3 us, row-tap loads 2.1 us of a 32.7 us launch.)
 template <class G, int MODE>
 __global__ __launch_bounds__(kThreads) void k_fovea_fixed(G g, FovParams p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    const int j = blockIdx.x, n = blockIdx.y, tid = threadIdx.x;
+    const int sl = blockIdx.x, n = blockIdx.y, tid = threadIdx.x;
     const int oh = g.oh(), ow = g.ow(), fh = g.fh(), fw = g.fw();
     if (p.mask && !p.mask[n]) {
-        if (j == 0 && tid < 2) p.loc_out[2 * n + tid] = p.loc_in[2 * n + tid];
+        if (sl == 0 && tid < 2) p.loc_out[2 * n + tid] = p.loc_in[2 * n + tid];
         return;
     }
+    // LDS carve: lut[256] | raw[oh*ow] u8 | ytab[oh] | H[fh][ow]
+    float *lut = reinterpret_cast<float *>(smem);
+    unsigned char *raw = smem + 1024;
+    const int fbytes = oh * ow;                                       // multiple of 4 (ow % 4 == 0)
+    const int raw_pad = (fbytes + 15) & ~15;
+    Tap *ytab_s = reinterpret_cast<Tap *>(raw + raw_pad);
+    float *H = reinterpret_cast<float *>(ytab_s + oh);
+
+    // ---- every round trip starts now: the frame, the taps, then the small state loads.  (The first
+    // use of the state waits for everything older too, which is fine: all of it is needed before the
+    // LDS image can be written; what matters is that nothing waits before everything is issued.)
+    const uint32_t *fsrc = reinterpret_cast<const uint32_t *>(p.ring + ((size_t)n * p.fs + sl) * (size_t)fbytes);
+    const int fwords = fbytes >> 2;
+    constexpr int kFW = 7;                                            // 7 * 256 dwords cover 84x84; loop beyond
+    uint32_t fw_[kFW];
+#pragma unroll
+    for (int k = 0; k < kFW; ++k) fw_[k] = fsrc[min(tid + k * kThreads, fwords - 1)];
+    const int xcol = tid % ow, yb = tid / ow;                         // phase-C column / first row
+    int4 xt = make_int4(0, 0, 0, 0), yt = xt;                         // raw Tap bits {lo, aux, a, b}
+    if (MODE == AGX_OUT_RESIZE) {
+        xt = *reinterpret_cast<const int4 *>(p.xtab + xcol);
+        yt = *reinterpret_cast<const int4 *>(p.ytab + min(tid, oh - 1));
+    }
+    const LocIn lin = load_loc_inputs(p, n);
+    const int head = p.head[n];
+    lut[tid] = unit((uint32_t)tid);
     int r, c;
-    next_loc(p, n, oh - fh, ow - fw, r, c);
-    if (j == 0 && tid == 0) {
+    compute_loc(p, lin, oh - fh, ow - fw, r, c);
+    int j = sl - head;                                                // stack position of this slot
+    if (j < 0) j += p.fs;
+    if (sl == 0 && tid == 0) {
         p.loc_out[2 * n] = r;
         p.loc_out[2 * n + 1] = c;
         if (p.user_loc) {
@@ -428,18 +566,23 @@ __global__ __launch_bounds__(kThreads) void k_fovea_fixed(G g, FovParams p) {
             p.user_loc[2 * n + 1] = c;
         }
     }
-    int slot = p.head[n] + j;
-    if (slot >= p.fs) slot -= p.fs;
-    const size_t fsz = (size_t)oh * ow;
-    const uint8_t *frame = p.ring + ((size_t)n * p.fs + slot) * fsz;
-
-    float *s = reinterpret_cast<float *>(smem);                      // [fh][fw]
-    stage_window(frame, ow, r, c, fh, fw, s, tid);
+#pragma unroll
+    for (int k = 0; k < kFW; ++k)
+        if (tid + k * kThreads < fwords) reinterpret_cast<uint32_t *>(raw)[tid + k * kThreads] = fw_[k];
+    for (int i = tid + kFW * kThreads; i < fwords; i += kThreads) reinterpret_cast<uint32_t *>(raw)[i] = fsrc[i];
+    if (MODE == AGX_OUT_RESIZE) {
+        if (tid < oh) *reinterpret_cast<int4 *>(ytab_s + tid) = yt;
+        for (int i = tid + kThreads; i < oh; i += kThreads) ytab_s[i] = p.ytab[i];
+    }
     __syncthreads();
 
+    const unsigned char *win = raw + r * ow + c;                      // window origin inside the frame
     if (MODE == AGX_OUT_RAW) {
         float *out = p.obs + ((size_t)n * p.fs + j) * (size_t)(fh * fw);
-        for (int i = tid; i < fh * fw; i += kThreads) out[i] = s[i];
+        for (int i = tid; i < fh * fw; i += kThreads) {
+            const int y = i / fw, x = i - y * fw;
+            out[i] = lut[win[y * ow + x]];
+        }
         return;
     }
     const int ow4 = ow >> 2;
@@ -447,32 +590,41 @@ __global__ __launch_bounds__(kThreads) void k_fovea_fixed(G g, FovParams p) {
     if (MODE == AGX_OUT_MASK) {
         for (int q = tid; q < oh * ow4; q += kThreads) {
             const int row = q / ow4, x = (q - row * ow4) * 4;
-            const int y = row - r;
             float v[4] = {0.f, 0.f, 0.f, 0.f};
-            if (y >= 0 && y < fh) {
+            if (row >= r && row < r + fh && x + 3 >= c && x < c + fw) {
+                const uint32_t w = *reinterpret_cast<const uint32_t *>(raw + row * ow + x);
 #pragma unroll
-                for (int k = 0; k < 4; ++k) {
-                    const int xx = x + k - c;
-                    if (xx >= 0 && xx < fw) v[k] = s[y * fw + xx];
-                }
+                for (int k = 0; k < 4; ++k)
+                    if (x + k >= c && x + k < c + fw) v[k] = lut[(w >> (8 * k)) & 0xFF];
             }
-            out4[q] = make_float4(v[0], v[1], v[2], v[3]);
+            store_obs(&out4[q], make_float4(v[0], v[1], v[2], v[3]));
         }
         return;
     }
-    // AGX_OUT_RESIZE
-    const int s_floats = (fh * fw + 3) & ~3;
-    float *H = s + s_floats;                                          // [fh][ow], 16-B aligned rows
-    for (int i = tid; i < fh * ow; i += kThreads) {
-        const int y = i / ow, x = i - y * ow;
-        const Tap t = p.xtab[x];
-        H[i] = t.a * s[y * fw + t.lo] + t.b * s[y * fw + t.aux];
+    // ---- RESIZE, phase C: thread owns column xcol (taps in registers), rows yb, yb + rstep, ...
+    const int rstep = kThreads / ow;                                  // 3 for ow = 84
+    if (rstep > 0) {
+        if (yb < rstep) {
+            const unsigned char *c0 = win + xt.x, *c1 = win + xt.y;
+            const float wa = __int_as_float(xt.z), wb = __int_as_float(xt.w);
+#pragma unroll 10
+            for (int y = yb; y < fh; y += rstep)
+                H[y * ow + xcol] = wa * lut[c0[y * ow]] + wb * lut[c1[y * ow]];
+        }
+    } else {                                                          // ow > 256: generic striding
+        for (int i = tid; i < fh * ow; i += kThreads) {
+            const int y = i / ow, x = i - y * ow;
+            const Tap t = p.xtab[x];
+            H[i] = t.a * lut[win[y * ow + t.lo]] + t.b * lut[win[y * ow + t.aux]];
+        }
     }
     __syncthreads();
+    // ---- phase D
     const float4 *H4 = reinterpret_cast<const float4 *>(H);
+#pragma unroll 7
     for (int q = tid; q < oh * ow4; q += kThreads) {
         const int row = q / ow4, x4 = q - row * ow4;
-        const Tap t = p.ytab[row];
+        const Tap t = ytab_s[row];
         const float4 a = H4[t.lo * ow4 + x4];
         const float4 b = H4[t.aux * ow4 + x4];
         float4 o;
@@ -480,7 +632,7 @@ __global__ __launch_bounds__(kThreads) void k_fovea_fixed(G g, FovParams p) {
         o.y = t.a * a.y + t.b * b.y;
         o.z = t.a * a.z + t.b * b.z;
         o.w = t.a * a.w + t.b * b.w;
-        out4[q] = o;
+        store_obs(&out4[q], o);
     }
 }
 
