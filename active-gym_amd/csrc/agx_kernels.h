@@ -54,6 +54,23 @@ __device__ __forceinline__ float unit(uint32_t k) { return (float)k / 255.0f; }
 // K1: ingest
 // ---------------------------------------------------------------------------------------------
 
+// Wave-uniform byte through the scalar cache.  hipcc emits a VECTOR load + s_waitcnt vmcnt(0) for
+// `p.cmd[n]` (it cannot prove the buffer read-only), i.e. a full memory round trip in front of the
+// first frame load of every workgroup; s_load_dword is counted on lgkmcnt and served by the scalar
+// cache.  Reads the aligned dword that contains the byte (same 4-byte word, never crosses a page).
+__device__ __forceinline__ uint32_t uniform_load_u8(const uint8_t *ptr) {
+    const uintptr_t a = reinterpret_cast<uintptr_t>(ptr);
+    const uint32_t *aligned = reinterpret_cast<const uint32_t *>(a & ~(uintptr_t)3);
+    uint32_t w;
+    asm volatile("s_load_dword %0, %1, 0x0\n\ts_waitcnt lgkmcnt(0)" : "=s"(w) : "s"(aligned) : "memory");
+    return (w >> (8 * (uint32_t)(a & 3))) & 0xFFu;
+}
+__device__ __forceinline__ int32_t uniform_load_i32(const int32_t *ptr) {
+    int32_t w;
+    asm volatile("s_load_dword %0, %1, 0x0\n\ts_waitcnt lgkmcnt(0)" : "=s"(w) : "s"(ptr) : "memory");
+    return w;
+}
+
 // ALE ColourPalette luminance: (uint8) round(r*0.2989 + g*0.5870 + b*0.1140) in C double.
 // The rational value (2989r+5870g+1140b)/10000 decides everything except exact .5 ties, where
 // the double evaluation sometimes lands below the tie (292 of 2^24 inputs); those are replayed
@@ -128,8 +145,12 @@ __global__ __launch_bounds__(T) void k_ingest(IngestParams p) {
     const int n = blockIdx.y;
     const int band = blockIdx.x;
     const int tid = threadIdx.x;
-    const uint32_t cmd = p.cmd[n];
-    const int head = p.head_in[n];
+#if defined(AGX_ABL) && AGX_ABL == 13
+    const uint32_t cmd = 2; const int head = n & 3;
+#else
+    const uint32_t cmd = uniform_load_u8(p.cmd + n);
+    const int head = uniform_load_i32(p.head_in + n);
+#endif
     const bool skip = (cmd & AGX_CMD_SKIP) != 0;
     const bool clear = (cmd & AGX_CMD_CLEAR) != 0;
     if (band == 0 && tid == 0) p.head_out[n] = skip ? head : (clear ? 0 : (head + 1 == p.fs ? 0 : head + 1));
@@ -199,8 +220,12 @@ __global__ __launch_bounds__(T) void k_ingest(IngestParams p) {
 #pragma unroll
         for (int it = 0; it < kIter; ++it) {
             bool tie = false;
+#if defined(AGX_ABL) && AGX_ABL == 11
+            const uint32_t top = w0[it].x ^ w0[it].y ^ w0[it].z, bot = w1[it].x ^ w1[it].y ^ w1[it].z;
+#else
             const uint32_t top = lum4(w0[it].x, w0[it].y, w0[it].z, tie);
             const uint32_t bot = lum4(w1[it].x, w1[it].y, w1[it].z, tie);
+#endif
             if (dst[it] >= 0) {
                 uint2 v;                                                  // t0 b0 t1 b1 | t2 b2 t3 b3
                 v.x = __builtin_amdgcn_perm(bot, top, 0x05010400u);
@@ -257,6 +282,9 @@ __global__ __launch_bounds__(T) void k_ingest(IngestParams p) {
         uint32_t packed = 0;
         const int xi[4] = {xt01.x, xt01.z, xt23.x, xt23.z};
         const int xa[4] = {xt01.y, xt01.w, xt23.y, xt23.w};
+#if defined(AGX_ABL) && AGX_ABL == 12
+        packed = *reinterpret_cast<const uint32_t *>(gray + dyl * kRawW * 2 + xq * 4) + b0 + xi[0] + xa[3];
+#else
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
             const int x0 = xi[k] & 0xFFFF, x1 = xi[k] >> 16;
@@ -272,6 +300,7 @@ __global__ __launch_bounds__(T) void k_ingest(IngestParams p) {
             }
             packed |= (uint32_t)best << (8 * k);
         }
+#endif
         const size_t fsz = (size_t)p.oh * p.ow;
         uint8_t *env = p.ring + (size_t)n * p.fs * fsz;
         const size_t off = (size_t)dy * p.ow + xq * 4;
