@@ -1,0 +1,159 @@
+"""AtariHostRunner — the host half of N Atari envs: one emulator per env,
+stepped by a pool of worker threads (one per host core), writing raw RGB
+screens into a (pinned) staging buffer for the device ingest kernel.
+
+It reproduces, per env, the emulator-facing control flow of the reference's
+``AtariEnv._step`` / ``_reset`` (reference atari_env.py:84-148) — everything
+except the image arithmetic, which is what the HIP kernels do:
+
+  step : ``action_repeat`` x ``ale.act``; the screens after t==2 and t==3 are
+         sampled (whatever action_repeat is, reference atari_env.py:125-128);
+         early ``break`` on game over; life-loss terminal in training mode.
+  reset: life-loss reset (one no-op, stack kept) or full reset (stack zeroed,
+         ``random.randrange(30)`` no-ops from the GLOBAL ``random`` module like
+         the reference, fire-reset when the game has >= 3 actions); one screen.
+
+Each call returns the per-env command byte for ``agx_ingest``:
+``nvalid | CMD_CLEAR | CMD_SKIP`` (include/agx.h).
+"""
+from __future__ import annotations
+
+import os
+import random
+from concurrent.futures import ThreadPoolExecutor
+from typing import Callable, Optional, Sequence
+
+import numpy as np
+
+from . import _native as nat
+from .frame_source import RAW_H, RAW_W, make_emulator
+
+
+class AtariHostRunner:
+    def __init__(self, args, num_envs: int, frames: Optional[np.ndarray] = None,
+                 workers: Optional[int] = None, noop_fn: Optional[Callable[[], int]] = None,
+                 env_offset: int = 0):
+        self.args = args
+        self.num_envs = int(num_envs)
+        self.action_repeat = int(args.action_repeat)
+        self.clip_reward = bool(args.clip_reward)
+        self.training = True                    # reference atari_env.py:58: args.training is ignored
+        self.noop_fn = noop_fn or (lambda: random.randrange(30))     # reference atari_env.py:96
+        self.emulators = [make_emulator(args, env_offset + i) for i in range(self.num_envs)]
+        acts = [list(e.getMinimalActionSet()) for e in self.emulators]
+        self.actions = acts                     # index -> emulator action, reference atari_env.py:51-52
+        self.num_actions = len(acts[0])
+        self.lives = np.zeros(self.num_envs, np.int64)
+        self.life_termination = np.zeros(self.num_envs, bool)
+        if frames is None:
+            frames = np.zeros((self.num_envs, 2, RAW_H, RAW_W, 3), np.uint8)
+        assert frames.shape == (self.num_envs, 2, RAW_H, RAW_W, 3) and frames.dtype == np.uint8
+        self.frames = frames
+        n_workers = workers if workers is not None else min(self.num_envs, os.cpu_count() or 1)
+        self._pool = ThreadPoolExecutor(max_workers=n_workers) if n_workers > 1 else None
+        self._n_workers = max(1, n_workers)
+
+    # ------------------------------------------------------------------ helpers
+    def close(self):
+        if self._pool is not None:
+            self._pool.shutdown(wait=True)
+            self._pool = None
+
+    def train(self):
+        self.training = True
+
+    def eval(self):
+        self.training = False
+
+    def _grab(self, i, slot, buf=None):
+        e = self.emulators[i]
+        np.copyto((self.frames if buf is None else buf)[i, slot], e.getScreenRGB())
+
+    def _map(self, fn, idx: Sequence[int]):
+        idx = list(idx)
+        if self._pool is None or len(idx) <= 1:
+            for i in idx:
+                fn(i)
+            return
+        chunks = np.array_split(np.asarray(idx), min(self._n_workers, len(idx)))
+        futs = [self._pool.submit(lambda c=c: [fn(int(i)) for i in c]) for c in chunks if len(c)]
+        for f in futs:
+            f.result()
+
+    # ------------------------------------------------------------------ step   (atari_env.py:119-148)
+    def step(self, motor_actions) -> tuple:
+        n = self.num_envs
+        motor = np.asarray(motor_actions).reshape(n)
+        raw = np.zeros(n, np.float64)
+        done = np.zeros(n, bool)
+        cmd = np.zeros(n, np.uint8)
+
+        def one(i):
+            e = self.emulators[i]
+            a = self.actions[i][int(motor[i])]
+            reward, d, nvalid = 0, False, 0
+            for t in range(self.action_repeat):
+                reward += e.act(a)
+                if t == 2:
+                    self._grab(i, 0)
+                    nvalid = 1
+                elif t == 3:
+                    self._grab(i, 1)
+                    nvalid = 2
+                d = e.game_over()
+                if d:
+                    break
+            if self.training:
+                lives = e.lives()
+                if lives < self.lives[i] and lives > 0:
+                    self.life_termination[i] = not d
+                    d = True
+                self.lives[i] = lives
+            raw[i] = reward
+            done[i] = d
+            cmd[i] = nvalid
+
+        self._map(one, range(n))
+        ret = np.sign(raw) if self.clip_reward else raw.copy()      # atari_env.py:144
+        return ret, done, cmd, raw
+
+    # ------------------------------------------------------------------ reset  (atari_env.py:84-117)
+    def reset(self, idx: Optional[Sequence[int]] = None, out: Optional[np.ndarray] = None) -> np.ndarray:
+        """Reset the envs in `idx` (all by default).  The single reset screen of env i goes to
+        ``out[i, 0]`` (default: the step staging buffer)."""
+        n = self.num_envs
+        idx = list(range(n)) if idx is None else [int(i) for i in idx]
+        cmd = np.full(n, nat.CMD_SKIP, np.uint8)
+        # no-op counts are drawn on the calling thread, in env order, from the global RNG
+        noops = {i: (0 if self.life_termination[i] else int(self.noop_fn())) for i in idx}
+
+        def one(i):
+            e = self.emulators[i]
+            if self.life_termination[i]:
+                self.life_termination[i] = False
+                e.act(0)
+                clear = 0
+            else:
+                clear = nat.CMD_CLEAR
+                e.reset_game()
+                for _ in range(noops[i]):
+                    e.act(0)
+                    if e.game_over():
+                        e.reset_game()
+            if len(self.actions[i]) >= 3:
+                e.act(1)
+                if e.game_over():
+                    e.reset_game()
+                    e.act(2)
+                if e.game_over():
+                    e.reset_game()
+            self._grab(i, 0, out)
+            self.lives[i] = e.lives()
+            cmd[i] = 1 | clear
+
+        self._map(one, idx)
+        return cmd
+
+    def render(self, i=0, size=(256, 256)):
+        """Raw RGB screen of env i (the reference resizes it with cv2, atari_env.py:165-169)."""
+        return np.array(self.emulators[i].getScreenRGB(), copy=True)

@@ -1,0 +1,314 @@
+"""Batched active-vision Atari envs on one MI355X.
+
+The reference has no vectorization of its own; callers loop N Python envs
+through ``gymnasium.vector.SyncVectorEnv`` (reference atari_env.py:241,276).
+:class:`AtariVecEnv` replaces that loop: N emulators on host cores
+(:class:`~active_gym.runner.AtariHostRunner`), raw screens staged through a
+pinned buffer and copied asynchronously to HBM, and the whole observation
+pipeline as HIP kernels (:class:`~active_gym.pipeline.ObsPipeline`).
+
+It keeps the SyncVectorEnv conventions of gymnasium<1.0 (setup.py:15 of the
+reference pins ``gymnasium>=0.28.1,<1.0.0``):
+  * ``step({"motor_action": (N,), "sensory_action": (N,2)[, "sensory_action_type": (N,)|(N,1)]})``
+    -> ``obs (N,fs,h,w) f32, reward (N,), terminated (N,), truncated (N,), infos``
+  * infos is a dict of arrays with ``_key`` masks; done envs are reset inside
+    the same call and their last observation / info are returned under
+    ``final_observation`` / ``final_info``.
+"""
+from __future__ import annotations
+
+from typing import Optional
+
+import numpy as np
+import torch
+
+from . import _native as nat
+from .pipeline import ObsPipeline
+from .runner import AtariHostRunner
+from .spaces import Box, Dict, Discrete
+
+_KINDS = ("base", "fixed", "flexible", "peripheral")
+
+
+def _resolve_antialias(args):
+    """torchvision's Resize default: antialias=True from 0.17 on (the reference leaves the version
+    unpinned, setup.py:17).  ``args.antialias`` overrides."""
+    return bool(getattr(args, "antialias", True))
+
+
+class AtariVecEnv:
+    """N envs of one kind.  ``args`` is an ``AtariEnvArgs``; extra optional attributes:
+    ``frame_source`` ("ale" | "synthetic" | factory), ``device`` (None -> NumPy outputs on the host like
+    the reference; a cuda device -> torch tensors that stay in HBM), ``antialias``, ``num_workers``."""
+
+    def __init__(self, args, num_envs: int, kind: str = "fixed", env_offset: int = 0, noop_fn=None,
+                 autoreset: bool = True):
+        self.autoreset = bool(autoreset)        # False: single-env semantics, the caller calls reset()
+        if kind not in _KINDS:
+            raise ValueError(f"kind must be one of {_KINDS}")
+        if not torch.cuda.is_available():
+            raise RuntimeError("active_gym envs need a ROCm GPU: the observation pipeline has no CPU implementation")
+        self.args = args
+        self.kind = kind
+        self.num_envs = int(num_envs)
+        self.obs_size = tuple(int(v) for v in args.obs_size)
+        if self.obs_size[0] != self.obs_size[1]:
+            # reference: cv2.resize(dsize=obs_size) yields (obs_size[1], obs_size[0]) and the assignment into
+            # frame_buffer raises (atari_env.py:74,121-128)
+            raise ValueError(f"obs_size {self.obs_size} must be square for Atari (cv2.resize takes (width, height))")
+        self.frame_stack = int(args.frame_stack)
+        self.action_repeat = int(args.action_repeat)
+        dev = getattr(args, "device", None)
+        self._numpy_out = dev is None
+        self.device = torch.device(dev) if dev is not None else torch.device("cuda", torch.cuda.current_device())
+        if self.device.index is None:
+            self.device = torch.device("cuda", torch.cuda.current_device())
+
+        kw = dict(num_envs=self.num_envs, kind=kind, obs_size=self.obs_size, frame_stack=self.frame_stack,
+                  device=self.device)
+        if kind != "base":
+            # these have no defaults in the reference and are read unconditionally (fov_env.py:110-120)
+            self.fov_size = tuple(int(v) for v in args.fov_size)
+            self.fov_init_loc = tuple(args.fov_init_loc)
+            self.sensory_action_mode = args.sensory_action_mode
+            if self.sensory_action_mode == "relative":
+                self.sensory_action_space = np.array(args.sensory_action_space)          # fov_env.py:116
+            elif self.sensory_action_mode == "absolute":
+                self.sensory_action_space = np.array(self.obs_size) - np.array(self.fov_size)   # fov_env.py:118
+            else:
+                raise ValueError("sensory_action_mode must be 'absolute' or 'relative'")
+            resize_to_full = bool(args.resize_to_full)
+            mask_out = bool(args.mask_out)
+            kw.update(fov_size=self.fov_size, fov_init_loc=self.fov_init_loc,
+                      sensory_action_mode=self.sensory_action_mode,
+                      sensory_action_space=tuple(np.asarray(args.sensory_action_space, dtype=float))
+                      if self.sensory_action_mode == "relative" else None,
+                      resize_to_full=resize_to_full, mask_out=mask_out, antialias=_resolve_antialias(args))
+            if kind == "peripheral":
+                self.peripheral_res = tuple(int(v) for v in args.peripheral_res)
+                kw["peripheral_res"] = self.peripheral_res
+                mask_out, resize_to_full = False, True                                  # fov_env.py:361-362
+            self.mask_out, self.resize_to_full = mask_out, resize_to_full
+        self.pipe = ObsPipeline(**kw)
+
+        # host side: pinned staging for step frames and for reset frames, device twins
+        shape = (self.num_envs, 2, nat.RAW_H, nat.RAW_W, 3)
+        self._h_frames = torch.empty(shape, dtype=torch.uint8, pin_memory=True)
+        self._d_frames = torch.empty(shape, dtype=torch.uint8, device=self.device)
+        # reset screens get their own pinned buffer: the autoreset inside step() must not overwrite step
+        # screens whose asynchronous H2D copy may still be in flight
+        self._h_rframes = torch.empty((self.num_envs, 1, nat.RAW_H, nat.RAW_W, 3), dtype=torch.uint8, pin_memory=True)
+        self._h_rcmd = torch.empty((self.num_envs,), dtype=torch.uint8, pin_memory=True)
+        self._ev_copy = torch.cuda.Event()
+        self._ev_rcopy = torch.cuda.Event()
+        self._h_cmd = torch.empty((self.num_envs,), dtype=torch.uint8, pin_memory=True)
+        self._d_cmd = torch.empty((self.num_envs,), dtype=torch.uint8, device=self.device)
+        self.runner = AtariHostRunner(args, self.num_envs, frames=self._h_frames.numpy(),
+                                      workers=getattr(args, "num_workers", None), noop_fn=noop_fn,
+                                      env_offset=env_offset)
+
+        # spaces (reference atari_env.py:69-70, fov_env.py:125-142,243)
+        n_act = self.runner.num_actions
+        self.single_motor_space = Discrete(n_act)
+        full = (self.frame_stack,) + self.obs_size
+        if kind == "base":
+            self.single_action_space = self.single_motor_space
+            self.single_observation_space = Box(low=-1., high=1., shape=full, dtype=np.float32)
+        else:
+            sas = self.sensory_action_space
+            spaces = {"motor_action": self.single_motor_space,
+                      "sensory_action": Box(low=sas[0], high=sas[1], dtype=int)}      # scalar Box, as the reference
+            if kind == "flexible":
+                spaces["sensory_action_type"] = Discrete(2)
+            self.single_action_space = Dict(spaces)
+            crop = kind == "fixed" and not (self.mask_out or self.resize_to_full)
+            shp = (self.frame_stack,) + (self.fov_size if crop else self.obs_size)
+            self.single_observation_space = Box(low=-1., high=1., shape=shp, dtype=np.float32)
+        self.action_space = self.single_action_space
+        self.observation_space = self.single_observation_space
+
+        # RecordWrapper bookkeeping (fov_env.py:29-32,58-63)
+        self.cumulative_reward = np.zeros(self.num_envs, np.float64)
+        self.ep_len = np.zeros(self.num_envs, np.int64)
+        self._obs = torch.empty(self.pipe.obs_shape if kind != "base" else self.pipe.full_shape,
+                                dtype=torch.float32, device=self.device)
+        self._loc = torch.zeros((self.num_envs, 2), dtype=torch.int32, device=self.device)
+        self._res = torch.zeros((self.num_envs, 2), dtype=torch.int32, device=self.device)
+        self._was_reset = False
+
+    # ------------------------------------------------------------------ plumbing
+    def close(self):
+        self.runner.close()
+        self.pipe.close()
+
+    def train(self):
+        self.runner.train()
+
+    def eval(self):
+        self.runner.eval()
+
+    @property
+    def fov_loc(self) -> np.ndarray:
+        return self.pipe.fov_state()[0].cpu().numpy()
+
+    @property
+    def fov_res(self) -> np.ndarray:
+        return self.pipe.fov_state()[1].cpu().numpy()
+
+    def _upload(self, cmd: np.ndarray):
+        """Asynchronous H2D of the step screens and the command bytes (pinned -> HBM, current stream)."""
+        self._h_cmd.numpy()[:] = cmd
+        self._d_cmd.copy_(self._h_cmd, non_blocking=True)
+        self._d_frames.copy_(self._h_frames, non_blocking=True)
+        self._ev_copy.record()
+
+    def _upload_reset(self, cmd: np.ndarray, idx):
+        """H2D of the reset screens of the envs in `idx` (slot 0 only) and their command bytes."""
+        self._h_rcmd.numpy()[:] = cmd
+        self._d_cmd.copy_(self._h_rcmd, non_blocking=True)
+        if idx is None:                     # every env: one strided copy
+            self._d_frames[:, 0].copy_(self._h_rframes[:, 0], non_blocking=True)
+        else:
+            for i in idx:
+                self._d_frames[int(i), 0].copy_(self._h_rframes[int(i), 0], non_blocking=True)
+        self._ev_rcopy.record()
+
+    def _as_device_action(self, a, cols):
+        if isinstance(a, torch.Tensor):
+            t = a.detach()
+        else:
+            t = torch.from_numpy(np.ascontiguousarray(np.asarray(a)))
+        if t.dtype == torch.float16 or t.dtype == torch.bfloat16:
+            t = t.float()
+        if t.dtype in (torch.int8, torch.int16, torch.uint8, torch.bool):
+            t = t.to(torch.int32)
+        t = t.reshape(self.num_envs, cols) if cols else t.reshape(self.num_envs)
+        return t.to(self.device, non_blocking=True).contiguous()
+
+    def _observe(self, action=None, action_type=None, mask=None, out=None):
+        out = self._obs if out is None else out
+        if self.kind == "base":
+            self.pipe.observe_full(out)
+        elif self.kind == "flexible":
+            self.pipe.fovea(action, action_type=action_type, mask=mask, out=out, loc_out=self._loc, res_out=self._res)
+        else:
+            self.pipe.fovea(action, mask=mask, out=out, loc_out=self._loc)
+        return out
+
+    def _out(self, t: torch.Tensor):
+        return t.cpu().numpy() if self._numpy_out else t
+
+    def _info(self, raw_reward):
+        info = {"raw_reward": np.asarray(raw_reward, dtype=np.float64).copy(),
+                "reward": self.cumulative_reward.copy(), "ep_len": self.ep_len.copy()}
+        if self.kind != "base":
+            info["fov_loc"] = self._loc.cpu().numpy().astype(np.int64)
+            if self.kind == "flexible":
+                info["fov_res"] = self._res.cpu().numpy().astype(np.int64)
+        return info
+
+    @staticmethod
+    def _with_masks(info, n):
+        out = {}
+        for k, v in info.items():
+            out[k] = v
+            out["_" + k] = np.ones(n, bool)
+        return out
+
+    # ------------------------------------------------------------------ API
+    def reset(self, seed=None, options=None):
+        """Reset every env (the reference ignores seed/options too, atari_env.py:150-152)."""
+        self._ev_copy.synchronize()
+        self._ev_rcopy.synchronize()
+        cmd = self.runner.reset(out=self._h_rframes.numpy())
+        self._upload_reset(cmd, None)
+        self.pipe.ingest(self._d_frames, self._d_cmd)
+        self.cumulative_reward[:] = 0
+        self.ep_len[:] = 0
+        if self.kind != "base":
+            self.pipe.fovea_reset()
+        obs = self._observe()
+        self._was_reset = True
+        return self._out(obs.clone() if not self._numpy_out else obs), self._with_masks(self._info(np.zeros(self.num_envs)),
+                                                                                       self.num_envs)
+
+    def step(self, action):
+        if not self._was_reset:
+            raise RuntimeError("call reset() before step()")
+        n = self.num_envs
+        if self.kind == "base":
+            motor, sens, stype = action, None, None
+        else:
+            motor = action["motor_action"]
+            sens = self._as_device_action(action["sensory_action"], 2)
+            stype = None
+            if self.kind == "flexible":
+                stype = self._as_device_action(action["sensory_action_type"], 0).to(torch.int32)
+        if isinstance(motor, torch.Tensor):
+            motor = motor.detach().cpu().numpy()
+        self._ev_copy.synchronize()             # the previous step's screens have left the pinned buffer
+        reward, done, cmd, raw = self.runner.step(motor)
+        self._upload(cmd)
+        self.pipe.ingest(self._d_frames, self._d_cmd)
+        obs = self._observe(sens, stype)
+        self.ep_len += 1
+        self.cumulative_reward += raw                   # unclipped, fov_env.py:62
+        info = self._info(raw)
+        truncated = np.zeros(n, bool)                   # always False, atari_env.py:145
+        infos = self._with_masks(info, n)
+        if self.autoreset and done.any():
+            idx = np.nonzero(done)[0]
+            final_obs_t = obs[torch.from_numpy(idx).to(self.device)].clone()
+            final_obs = np.empty(n, dtype=object)
+            final_info = np.empty(n, dtype=object)
+            fo = self._out(final_obs_t)
+            for k, i in enumerate(idx):
+                final_obs[i] = fo[k]
+                final_info[i] = {key: (val[i].copy() if isinstance(val[i], np.ndarray) else val[i])
+                                 for key, val in info.items()}
+            # env.reset() of the done envs inside the same step (SyncVectorEnv, gymnasium<1.0)
+            self._ev_rcopy.synchronize()
+            cmd2 = self.runner.reset(idx, out=self._h_rframes.numpy())
+            self._upload_reset(cmd2, idx)
+            self.pipe.ingest(self._d_frames, self._d_cmd)
+            self.cumulative_reward[idx] = 0
+            self.ep_len[idx] = 0
+            mask = torch.from_numpy(done.astype(np.uint8)).to(self.device)
+            if self.kind == "base":
+                self._observe()
+            else:
+                self.pipe.fovea_reset(mask)
+                self._observe(None, None, mask=mask)
+            rinfo = self._info(np.zeros(n))
+            for key in info:
+                infos[key] = np.where(done.reshape((n,) + (1,) * (info[key].ndim - 1)), rinfo[key], info[key])
+            infos["final_observation"] = final_obs
+            infos["_final_observation"] = done.copy()
+            infos["final_info"] = final_info
+            infos["_final_info"] = done.copy()
+        out = self._out(obs if self._numpy_out else obs.clone())
+        return out, reward, done, truncated, infos
+
+    def reset_envs(self, idx):
+        """Reset only the envs in `idx` (what a caller without autoreset does after `done`)."""
+        idx = [int(i) for i in idx]
+        n = self.num_envs
+        self._ev_rcopy.synchronize()
+        cmd = self.runner.reset(idx, out=self._h_rframes.numpy())
+        self._upload_reset(cmd, idx)
+        self.pipe.ingest(self._d_frames, self._d_cmd)
+        self.cumulative_reward[idx] = 0
+        self.ep_len[idx] = 0
+        m = np.zeros(n, np.uint8)
+        m[idx] = 1
+        mask = torch.from_numpy(m).to(self.device)
+        if self.kind == "base":
+            obs = self._observe()
+        else:
+            self.pipe.fovea_reset(mask)
+            obs = self._observe(None, None, mask=mask)
+        self._was_reset = True
+        return self._out(obs if self._numpy_out else obs.clone()), self._with_masks(self._info(np.zeros(n)), n)
+
+    def render(self, index=0):
+        return self.runner.render(index)

@@ -119,6 +119,25 @@ def cpu_baseline(budget_s, seed):
             "sample": f"{n} envs x {reps} steps of the same config through {impl}, {el:.1f} s"}
 
 
+def barrier(dist, local_rank):
+    """All ranks rendezvous (no-op for a single process)."""
+    if dist is not None and dist.is_initialized() and dist.get_world_size() > 1:
+        if local_rank is None:
+            dist.barrier()
+        else:
+            dist.barrier(device_ids=[local_rank])
+
+
+def max_over_ranks(value, dist, device):
+    """MAX of a per-rank scalar (the timed region's duration) over all ranks."""
+    if dist is None or not dist.is_initialized() or dist.get_world_size() == 1:
+        return float(value)
+    import torch
+    t = torch.tensor([value], dtype=torch.float64, device=device)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    return float(t.item())
+
+
 def relaunch_under_torchrun(args):
     """`python bench.py --gpus N` without a launcher: start the ranks as a child job (nothing here has
     touched the GPU yet) and exit with its code."""
@@ -168,16 +187,12 @@ def main():
         else:
             pipe.fovea(acts[i], action_type=types[i], out=obs, loc_out=loc, res_out=res_out)
 
-    def barrier():
-        if dist is not None:
-            dist.barrier(device_ids=[local_rank])
-
     for k in range(args.warmup):
         step(k)
     K = args.steps
     use_ev = not args.no_events
     ev = [[torch.cuda.Event(enable_timing=True) for _ in range(3)] for _ in range(K)] if use_ev else None
-    barrier()
+    barrier(dist, local_rank)
     torch.cuda.synchronize(dev)
     t0 = time.perf_counter()
     if use_ev:
@@ -198,11 +213,8 @@ def main():
             step(k)
     torch.cuda.synchronize(dev)
     elapsed = time.perf_counter() - t0
-    barrier()
-    if dist is not None:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+    barrier(dist, local_rank)
+    elapsed = max_over_ranks(elapsed, dist, dev)
 
     out = None
     if rank == 0:

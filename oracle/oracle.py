@@ -237,7 +237,8 @@ class AtariEnvOracle:
     def __init__(self, ale, n_actions_minimal: Sequence[int], obs_size=(84, 84),
                  frame_stack=4, action_repeat=4, clip_reward=False,
                  noop_fn: Optional[Callable[[], int]] = None,
-                 resize_fn: Optional[Callable[[np.ndarray], np.ndarray]] = None):
+                 resize_fn: Optional[Callable[[np.ndarray], np.ndarray]] = None, prefer_rgb: bool = False):
+        self.prefer_rgb = prefer_rgb            # luminance of getScreenRGB instead of getScreenGrayscale
         self.ale = ale
         acts = list(n_actions_minimal)
         self.actions = dict(zip(range(len(acts)), acts))   # atari_env.py:51-52
@@ -253,7 +254,7 @@ class AtariEnvOracle:
         self.resize_fn = resize_fn or (lambda g: cv_resize_linear_u8(g, (self.obs_size[0], self.obs_size[1])))
 
     def _gray(self):
-        if hasattr(self.ale, "getScreenGrayscale"):
+        if hasattr(self.ale, "getScreenGrayscale") and not self.prefer_rgb:
             g = np.asarray(self.ale.getScreenGrayscale())
             return g[..., 0] if g.ndim == 3 else g
         return ale_luminance(np.asarray(self.ale.getScreenRGB()))

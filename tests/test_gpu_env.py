@@ -1,0 +1,239 @@
+"""GPU: the drop-in env API end to end (host runner -> pinned staging -> H2D ->
+HIP ingest + fovea kernels) against the oracle's per-env chain
+``FovealOracle(RecordOracle(AtariEnvOracle(emulator)))`` driven by the same
+scripted emulators, same actions, same no-op draws.
+
+Bars: u8 stack / fov_loc / fov_res / rewards / dones / counters exact; float
+observations within 1e-5 (bit-exact for crop / mask modes)."""
+import numpy as np
+import pytest
+import torch
+
+from fake_ale import ScriptedALE
+from oracle import oracle as O
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-5
+
+
+def _args(**kw):
+    from active_gym import AtariEnvArgs
+    base = dict(game="scripted", seed=7, obs_size=(84, 84), frame_source=lambda a, i: ScriptedALE(seed=300 + i, n_actions=4,
+                                                                                                 p_life=0.05, p_over=0.01))
+    base.update(kw)
+    return AtariEnvArgs(**base)
+
+
+class _Noops:
+    """Two identical deterministic no-op streams (product runner / oracle envs)."""
+
+    def __init__(self, seed):
+        self.seq = np.random.default_rng(seed).integers(0, 30, size=10000).tolist()
+        self.a = iter(self.seq)
+        self.b = iter(self.seq)
+
+
+def _oracle_env(i, args, noop_iter, kind, antialias=True):
+    ale = ScriptedALE(seed=300 + i, n_actions=4, p_life=0.05, p_over=0.01)
+    env = O.AtariEnvOracle(ale, ale.getMinimalActionSet(), obs_size=(84, 84), frame_stack=args.frame_stack,
+                           action_repeat=args.action_repeat, clip_reward=args.clip_reward,
+                           noop_fn=lambda: int(next(noop_iter)), prefer_rgb=True)
+    rec = O.RecordOracle(env)
+    if kind == "base":
+        return rec, None
+    kw = dict(obs_size=(84, 84), fov_size=tuple(args.fov_size), fov_init_loc=tuple(args.fov_init_loc),
+              sensory_action_mode=args.sensory_action_mode,
+              sensory_action_space=getattr(args, "sensory_action_space", None), antialias=antialias)
+    if kind == "fixed":
+        fov = O.FixedFovealOracle(resize_to_full=args.resize_to_full, mask_out=args.mask_out, **kw)
+    elif kind == "flexible":
+        fov = O.FlexibleFovealOracle(resize_to_full=args.resize_to_full, mask_out=args.mask_out, **kw)
+    else:
+        fov = O.PeripheralOracle(peripheral_res=tuple(args.peripheral_res), **kw)
+    return rec, fov
+
+
+@pytest.mark.parametrize("kind,extra", [
+    ("fixed", dict(resize_to_full=True)),
+    ("fixed", dict(resize_to_full=False, mask_out=True, sensory_action_mode="relative", sensory_action_space=(-10.0, 10.0))),
+    ("peripheral", dict(resize_to_full=False, peripheral_res=(20, 20))),
+    ("flexible", dict(resize_to_full=True)),
+    ("base", dict()),
+])
+def test_vec_env_matches_oracle_with_autoreset(kind, extra):
+    from active_gym import AtariVecEnv
+    N, STEPS = 5, 60
+    kw = dict(fov_size=(30, 30), fov_init_loc=(3.5, 4.49), sensory_action_mode="absolute", resize_to_full=True)
+    kw.update(extra)
+    args = _args(**kw)
+    noops = _Noops(1)
+    env = AtariVecEnv(args, N, kind=kind, noop_fn=lambda: int(next(noops.a)))
+    orcs = [_oracle_env(i, args, noops.b, kind) for i in range(N)]
+    rng = np.random.default_rng(3)
+
+    def fov_obs(i, state, a=None, t=None, reset=False):
+        rec, fov = orcs[i]
+        if fov is None:
+            return state
+        if reset:
+            return fov.reset(state)
+        if kind == "flexible":
+            return fov.step(state, a, np.array((t,)))
+        return fov.step(state, a)
+
+    obs, infos = env.reset()
+    want = []
+    for i in range(N):                      # same env order as the runner draws its no-ops
+        s, info = orcs[i][0].reset()
+        want.append(fov_obs(i, s, reset=True))
+    assert obs.dtype == np.float32 and obs.shape[0] == N
+    np.testing.assert_allclose(obs, np.stack(want), rtol=0, atol=TOL)
+    n_done = 0
+    for step in range(STEPS):
+        motor = rng.integers(0, 4, N)
+        if args.__dict__.get("sensory_action_mode") == "relative":
+            sens = rng.uniform(-14, 14, (N, 2))
+        else:
+            sens = rng.uniform(-5, 60, (N, 2))
+        types = rng.integers(0, 2, N)
+        if kind == "flexible":
+            sens = np.where(types[:, None] == 1, rng.integers(8, 70, (N, 2)), np.rint(sens)).astype(np.int64)
+        act = motor if kind == "base" else {"motor_action": motor, "sensory_action": sens}
+        if kind == "flexible":
+            act["sensory_action_type"] = types.reshape(N, 1)
+        obs, rew, term, trunc, infos = env.step(act)
+        assert not trunc.any()
+        for i in range(N):
+            rec, fov = orcs[i]
+            s, r, d, tr, info = rec.step(int(motor[i]))
+            a_i = sens[i]
+            if kind == "flexible" and types[i] == 1:
+                a_i = np.clip(a_i, 1, 84)   # the ABI clamps FOV_RES into [1, obs]; the reference stores it raw
+            o = fov_obs(i, s, a_i, int(types[i]))
+            assert float(rew[i]) == float(r) and bool(term[i]) == bool(d), (step, i)
+            if d:
+                n_done += 1
+                assert infos["_final_observation"][i] and infos["_final_info"][i]
+                np.testing.assert_allclose(infos["final_observation"][i], o, rtol=0, atol=TOL)
+                fi = infos["final_info"][i]
+                assert fi["ep_len"] == info["ep_len"] and fi["reward"] == info["reward"] and fi["raw_reward"] == info["raw_reward"]
+                if fov is not None:
+                    assert np.array_equal(fi["fov_loc"], fov.fov_loc)
+                s, info = rec.reset()
+                o = fov_obs(i, s, reset=True)
+            np.testing.assert_allclose(obs[i], o, rtol=0, atol=TOL, err_msg=f"step {step} env {i}")
+            assert infos["ep_len"][i] == info["ep_len"] and infos["reward"][i] == info["reward"]
+            if fov is not None:
+                assert np.array_equal(infos["fov_loc"][i], fov.fov_loc), (step, i)
+                if kind == "flexible":
+                    assert np.array_equal(infos["fov_res"][i], fov.fov_res)
+        if kind != "base" and step % 10 == 0:
+            assert np.array_equal(env.fov_loc, np.stack([o_[1].fov_loc for o_ in orcs]))
+    assert n_done >= 2, "the scripted emulators should have produced terminals"
+    # the device u8 stack equals the oracle's state_buffer numerators
+    st = env.pipe.stack_u8().cpu().numpy()
+    for i in range(N):
+        full = np.stack(orcs[i][0].env.state_buffer, 0)
+        assert np.array_equal(st[i], np.rint(full * 255).astype(np.uint8))
+    env.close()
+
+
+@pytest.mark.parametrize("factory,kind,extra", [
+    ("AtariFixedFovealEnv", "fixed", dict(resize_to_full=True)),
+    ("AtariFixedFovealEnv", "fixed", dict(resize_to_full=False)),
+    ("AtariFlexibleFovealEnv", "flexible", dict(resize_to_full=False)),
+    ("AtariFixedFovealPeripheralEnv", "peripheral", dict(resize_to_full=False, peripheral_res=(20, 20))),
+    ("AtariBaseEnv", "base", dict()),
+])
+def test_single_env_drop_in(factory, kind, extra):
+    import active_gym
+    kw = dict(fov_size=(30, 30), fov_init_loc=(0, 0), sensory_action_mode="absolute", resize_to_full=True,
+              frame_stack=3, clip_reward=True)
+    kw.update(extra)
+    args = _args(**kw)
+    noops = _Noops(2)
+    env = getattr(active_gym, factory)(args)
+    env.unwrapped._core.runner.noop_fn = lambda: int(next(noops.a))
+    rec, fov = _oracle_env(0, args, noops.b, kind)
+    rng = np.random.default_rng(9)
+    if kind == "base":
+        obs, info = env.reset()
+    else:
+        obs, info = env.reset()
+        assert isinstance(info["fov_loc"], np.ndarray) and info["fov_loc"].shape == (2,)
+    s, oinfo = rec.reset()
+    want = s if fov is None else fov.reset(s)
+    assert obs.shape == want.shape and obs.dtype == np.float32
+    np.testing.assert_allclose(obs, want, rtol=0, atol=TOL)
+    assert info["ep_len"] == 0 and info["reward"] == 0
+    done_seen = 0
+    for step in range(80):
+        m = int(rng.integers(0, 4))
+        t = int(rng.integers(0, 2))
+        sa = rng.integers(10, 50, 2) if (kind == "flexible" and t == 1) else rng.uniform(-3, 58, 2)
+        if kind == "base":
+            obs, r, d, tr, info = env.step(m)
+        else:
+            a = {"motor_action": m, "sensory_action": sa if step % 2 else torch.from_numpy(np.asarray(sa))}
+            if kind == "flexible":
+                a["sensory_action_type"] = np.array((t,))
+            obs, r, d, tr, info = env.step(a)
+        s, orr, od, _, oinfo = rec.step(m)
+        if fov is None:
+            want = s
+        elif kind == "flexible":
+            want = fov.step(s, np.asarray(sa), np.array((t,)))
+        else:
+            want = fov.step(s, np.asarray(sa))
+        assert obs.shape == want.shape, (obs.shape, want.shape)
+        np.testing.assert_allclose(obs, want, rtol=0, atol=TOL)
+        assert r == orr and d == od and tr is False
+        assert info["raw_reward"] == oinfo["raw_reward"] and info["reward"] == oinfo["reward"] and info["ep_len"] == oinfo["ep_len"]
+        if fov is not None:
+            assert np.array_equal(info["fov_loc"], fov.fov_loc) and np.array_equal(env.fov_loc, fov.fov_loc)
+        if d:
+            done_seen += 1
+            obs, info = env.reset()
+            s, oinfo = rec.reset()
+            want = s if fov is None else fov.reset(s)
+            np.testing.assert_allclose(obs, want, rtol=0, atol=TOL)
+    assert done_seen >= 1
+    assert env.action_space is not None and env.observation_space.shape == obs.shape or kind == "flexible"
+    env.close()
+
+
+def test_device_outputs_and_synthetic_source():
+    from active_gym import AtariEnvArgs, AtariVecEnv
+    args = AtariEnvArgs(game="boxing", seed=0, obs_size=(84, 84), fov_size=(30, 30), fov_init_loc=(0, 0),
+                        sensory_action_mode="absolute", resize_to_full=True, frame_source="synthetic", device="cuda")
+    env = AtariVecEnv(args, 16, kind="fixed")
+    obs, infos = env.reset()
+    assert isinstance(obs, torch.Tensor) and obs.is_cuda and obs.shape == (16, 4, 84, 84)
+    for _ in range(5):
+        a = {"motor_action": np.random.randint(0, 4, 16), "sensory_action": torch.rand(16, 2, device="cuda") * 54}
+        obs, r, d, t, infos = env.step(a)
+    assert obs.is_cuda and float(obs.max()) <= 1.0 and float(obs.min()) >= 0.0 and float(obs.max()) > 0.0
+    assert infos["fov_loc"].shape == (16, 2) and (infos["ep_len"] <= 5).all() and (infos["ep_len"] == 5).any()
+    env.close()
+
+
+def test_recording_buffer_keys(tmp_path):
+    import active_gym
+    args = _args(fov_size=(30, 30), fov_init_loc=(0, 0), sensory_action_mode="absolute", resize_to_full=True, record=True)
+    env = active_gym.AtariFixedFovealEnv(args)
+    env.reset()
+    done = False
+    n = 0
+    while not done and n < 400:
+        obs, r, done, _, info = env.step({"motor_action": 1, "sensory_action": np.array((5, 7))})
+        n += 1
+    env.reset()                                  # moves the finished episode to prev_record_buffer
+    rw = env.env
+    buf = rw.prev_record_buffer
+    assert set(buf) >= {"rgb", "state", "action", "reward", "done", "truncated", "info", "return_reward", "fov_size", "fov_loc"}
+    assert buf["rgb"][0].shape == (256, 256, 3) and len(buf["action"]) == n
+    path = str(tmp_path / "rec.pt")
+    rw.save_record_to_file(path)
+    saved = torch.load(path, weights_only=False)
+    assert isinstance(saved["rgb"], str) and len(saved["reward"]) == n
+    env.close()
