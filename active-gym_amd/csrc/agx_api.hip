@@ -355,7 +355,17 @@ int agx_ingest(agx_ctx *ctx, const uint8_t *d_frames, const uint8_t *d_cmd, void
     p.y_shift = ctx->y_shift;
     const int bands = (c.obs_h + ctx->band_rows - 1) / ctx->band_rows;
     const size_t lds = sizeof(int4) * ctx->band_rows + sizeof(int2) * c.obs_w + (size_t)2 * ctx->band_rows * 2 * kRawW;
-    if (ctx->ingest_t == 128)
+    p.nbands = bands;
+    p.stamps = nullptr;
+#ifdef AGX_STAMPS
+    if (const char *e = getenv("AGX_DBG_PTR")) p.stamps = reinterpret_cast<unsigned long long *>(strtoull(e, nullptr, 0));
+#endif
+    static const int pipe_parts = [] { const char *e = getenv("AGX_INGEST_PIPE"); return e ? atoi(e) : 0; }();
+    if (pipe_parts > 0 && ctx->ingest_t == 256) {
+        const int parts = std::min(pipe_parts, bands);
+        const size_t lds2 = sizeof(int4) * c.obs_h + sizeof(int2) * c.obs_w + (size_t)2 * (2 * ctx->band_rows * 2 * kRawW);
+        hipLaunchKernelGGL(k_ingest_pipe<256>, dim3(parts, c.num_envs), dim3(256), lds2, S(stream), p);
+    } else if (ctx->ingest_t == 128)
         hipLaunchKernelGGL(k_ingest<128>, dim3(bands, c.num_envs), dim3(128), lds, S(stream), p);
     else
         hipLaunchKernelGGL(k_ingest<256>, dim3(bands, c.num_envs), dim3(256), lds, S(stream), p);

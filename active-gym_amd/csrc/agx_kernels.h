@@ -65,6 +65,20 @@ __device__ __forceinline__ uint32_t uniform_load_u8(const uint8_t *ptr) {
     asm volatile("s_load_dword %0, %1, 0x0\n\ts_waitcnt lgkmcnt(0)" : "=s"(w) : "s"(aligned) : "memory");
     return (w >> (8 * (uint32_t)(a & 3))) & 0xFFu;
 }
+// 24-bit multiply at full rate.  hipcc lowers __mul24 / __umul24 to the quarter-rate v_mul_lo_u32
+// whenever it cannot prove the operand ranges itself; every product on this path fits (operands < 2^24,
+// result < 2^32).
+__device__ __forceinline__ uint32_t mul_u24(uint32_t a, uint32_t b) {
+    uint32_t r;
+    asm("v_mul_u32_u24_e32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+__device__ __forceinline__ uint32_t mad_u24(uint32_t a, uint32_t b, uint32_t c) {
+    uint32_t r;
+    asm("v_mad_u32_u24 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+    return r;
+}
+
 __device__ __forceinline__ int32_t uniform_load_i32(const int32_t *ptr) {
     int32_t w;
     asm volatile("s_load_dword %0, %1, 0x0\n\ts_waitcnt lgkmcnt(0)" : "=s"(w) : "s"(ptr) : "memory");
@@ -89,9 +103,7 @@ __device__ __forceinline__ uint32_t ale_lum_px(uint32_t px /* r | g<<8 | b<<16 |
     const uint32_t hi = __builtin_amdgcn_udot4(px, kLumWHi, 0u, false);
     const uint32_t t = __builtin_amdgcn_udot4(px, kLumWLo, (hi << 8) + 5000u, false);
     const uint32_t q = (uint32_t)(((uint64_t)(t & 0xFFFFFFu) * 13743896ull) >> 32) >> 5;
-    uint32_t back;                       // q * 10000 at full rate (hipcc otherwise picks v_mul_lo_u32)
-    asm("v_mul_u32_u24_e32 %0, %1, %2" : "=v"(back) : "v"(q), "v"(10000u));
-    tie |= back == t;
+    tie |= mul_u24(q, 10000u) == t;
     return q;
 }
 
@@ -118,6 +130,8 @@ __device__ __forceinline__ uint32_t ale_lum_exact(uint32_t r, uint32_t g, uint32
     return q;
 }
 
+struct __attribute__((aligned(4))) U3 { uint32_t x, y, z; };
+
 struct IngestParams {
     const uint8_t *frames;   // [N][2][210][160][3]
     const uint8_t *cmd;      // [N]
@@ -128,10 +142,26 @@ struct IngestParams {
     const int4 *ytab;        // [oh]  {y0, y1, b0, b1}
     int32_t oh, ow, fs;
     int32_t band_rows;       // output rows per workgroup (band_rows * ow/4 <= 256, band_rows <= 12)
+    int32_t nbands;          // ceil(oh / band_rows)
     // y0(dy) == (dy * y_mul + y_add) >> y_shift and y1 == min(y0 + 1, raw_h - 1) for every dy (checked
     // exhaustively against ytab at agx_create); lets the frame loads start without a table round trip.
     int32_t y_affine, y_mul, y_add, y_shift;
+    unsigned long long *stamps;   // diagnostic builds only (AGX_STAMPS): [workgroup][wave][6] s_memtime values
 };
+
+#ifdef AGX_STAMPS
+#define AGX_STAMP(i)                                                                              \
+    do {                                                                                          \
+        __builtin_amdgcn_sched_barrier(0);                                                        \
+        unsigned long long t_;                                                                    \
+        asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory");               \
+        __builtin_amdgcn_sched_barrier(0);                                                        \
+        if (p.stamps && (threadIdx.x & 63) == 0)                                                  \
+            p.stamps[(((size_t)blockIdx.y * gridDim.x + blockIdx.x) * (T / 64) + (threadIdx.x >> 6)) * 6 + (i)] = t_; \
+    } while (0)
+#else
+#define AGX_STAMP(i) do {} while (0)
+#endif
 
 // grid = (bands, N), block = T threads (T = 128 or 256).  Per workgroup: the two source rows of each
 // of its output rows, for both frames, go HBM -> registers (12-byte / 4-pixel pieces, lane-contiguous)
@@ -145,20 +175,7 @@ __global__ __launch_bounds__(T) void k_ingest(IngestParams p) {
     const int n = blockIdx.y;
     const int band = blockIdx.x;
     const int tid = threadIdx.x;
-#if defined(AGX_ABL) && AGX_ABL == 13
-    const uint32_t cmd = 2; const int head = n & 3;
-#else
-    const uint32_t cmd = uniform_load_u8(p.cmd + n);
-    const int head = uniform_load_i32(p.head_in + n);
-#endif
-    const bool skip = (cmd & AGX_CMD_SKIP) != 0;
-    const bool clear = (cmd & AGX_CMD_CLEAR) != 0;
-    if (band == 0 && tid == 0) p.head_out[n] = skip ? head : (clear ? 0 : (head + 1 == p.fs ? 0 : head + 1));
-    if (skip) return;
-    int nvalid = cmd & AGX_CMD_NVALID_MASK;
-    if (nvalid > 2) nvalid = 2;
-    const int slot = clear ? p.fs - 1 : head;
-
+    AGX_STAMP(0);
     const int BR = p.band_rows;
     const int dy0 = band * BR;
     const int rows = min(BR, p.oh - dy0);
@@ -173,45 +190,64 @@ __global__ __launch_bounds__(T) void k_ingest(IngestParams p) {
 
     // phase 1: thread = (piece g4 of 40, row group rg of T/40); row job rj = rg + RG*it is (frame,
     // output row); it loads both source rows of that output row, 4 pixels wide -> 8 gray bytes in LDS.
-    // Loads are unconditional (row job clamped) so that all of a thread's loads are in flight before
-    // the first use; only the LDS store is predicated.
+    // The loads go out FIRST and unconditionally, as if both frames were wanted (stamps showed 40 % of
+    // a wave's life spent waiting for the per-env command byte before its first frame load): the
+    // command / ring-head scalar loads then complete underneath them; `skip` and `nvalid` only gate
+    // what is written.  (A skipped env costs its reads; sparse launches are rare and host-bound.)
     constexpr int G4 = kRawW / 4;                                         // 40 four-pixel pieces per row
     constexpr int RG = T / G4;                                            // row groups: 6 (T=256) / 3 (T=128)
     constexpr int kIter = 4;                                              // 2 frames * band_rows / RG
-    const int nrj = nvalid * rows;                                        // <= RG * kIter
-    struct __attribute__((aligned(4))) U3 { uint32_t x, y, z; };
-    if (nrj > 0) {
-        const int rg = tid / G4, g4 = tid - rg * G4;
-        const uint8_t *fbase = p.frames + (size_t)n * 2 * kRawFrameBytes;   // wave-uniform base
-        const uint32_t col = g4 * 12;
-        auto row_offsets = [&](int it, uint32_t &o0, uint32_t &o1, int &d) {
-            const int rj_raw = rg + RG * it;
-            const int rj = min(rj_raw, nrj - 1);
-            const int f = rj >= rows ? 1 : 0;                             // nvalid <= 2
-            const int dyl = rj - f * rows;
-            int y0, y1;
-            if (p.y_affine) {
-                y0 = ((dy0 + dyl) * p.y_mul + p.y_add) >> p.y_shift;
-                y1 = min(y0 + 1, kRawH - 1);
-            } else {
-                const int4 yt = ytab_s[dyl];
-                y0 = yt.x;
-                y1 = yt.y;
-            }
-            const uint32_t fo = f * kRawFrameBytes + col;                 // 32-bit lane offsets
-            o0 = fo + __umul24((uint32_t)y0, kRawRowBytes);
-            o1 = fo + __umul24((uint32_t)y1, kRawRowBytes);
-            d = (rj_raw < nrj && rg < RG) ? ((f * BR + dyl) * kRawW + g4 * 4) * 2 : -1;
-        };
-        U3 w0[kIter], w1[kIter];
-        int dst[kIter];
-#pragma unroll
-        for (int it = 0; it < kIter; ++it) {
-            uint32_t o0, o1;
-            row_offsets(it, o0, o1, dst[it]);
-            w0[it] = *reinterpret_cast<const U3 *>(fbase + o0);
-            w1[it] = *reinterpret_cast<const U3 *>(fbase + o1);
+    const int rg = tid / G4, g4 = tid - rg * G4;
+    const uint8_t *fbase = p.frames + (size_t)n * 2 * kRawFrameBytes;     // wave-uniform base
+    const uint32_t col = g4 * 12;
+    int nvalid = 2;                                                       // speculative until cmd arrives
+    auto row_offsets = [&](int it, uint32_t &o0, uint32_t &o1, int &d) {
+        const int nrj = max(nvalid, 1) * rows;
+        const int rj_raw = rg + RG * it;
+        const int rj = min(rj_raw, nrj - 1);
+        const int f = rj >= rows ? 1 : 0;                                 // nvalid <= 2
+        const int dyl = rj - f * rows;
+        int y0, y1;
+        if (p.y_affine) {
+            y0 = (int)(mul_u24((uint32_t)(dy0 + dyl), (uint32_t)p.y_mul) + (uint32_t)p.y_add) >> p.y_shift;
+            y1 = min(y0 + 1, kRawH - 1);
+        } else {
+            const int4 yt = ytab_s[dyl];
+            y0 = yt.x;
+            y1 = yt.y;
         }
+        const uint32_t fo = f * kRawFrameBytes + col;                     // 32-bit lane offsets
+        o0 = mad_u24((uint32_t)y0, kRawRowBytes, fo);
+        o1 = mad_u24((uint32_t)y1, kRawRowBytes, fo);
+        d = (rj_raw < nvalid * rows && rg < RG) ? ((f * BR + dyl) * kRawW + g4 * 4) * 2 : -1;
+    };
+    U3 w0[kIter], w1[kIter];
+    int dst[kIter];
+#pragma unroll
+    for (int it = 0; it < kIter; ++it) {
+        uint32_t o0, o1;
+        row_offsets(it, o0, o1, dst[it]);
+        w0[it] = *reinterpret_cast<const U3 *>(fbase + o0);
+        w1[it] = *reinterpret_cast<const U3 *>(fbase + o1);
+    }
+#if defined(AGX_ABL) && AGX_ABL == 13
+    const uint32_t cmd = 2; const int head = n & 3;
+#else
+    const uint32_t cmd = uniform_load_u8(p.cmd + n);
+    const int head = uniform_load_i32(p.head_in + n);
+#endif
+    const bool skip = (cmd & AGX_CMD_SKIP) != 0;
+    const bool clear = (cmd & AGX_CMD_CLEAR) != 0;
+    if (band == 0 && tid == 0) p.head_out[n] = skip ? head : (clear ? 0 : (head + 1 == p.fs ? 0 : head + 1));
+    if (skip) return;
+    nvalid = min((int)(cmd & AGX_CMD_NVALID_MASK), 2);
+    const int slot = clear ? p.fs - 1 : head;
+    const int nrj = nvalid * rows;
+    if (nrj > 0) {
+#pragma unroll
+        for (int it = 0; it < kIter; ++it)                                // frame-1 jobs are void when nvalid == 1
+            if (rg + RG * it >= nrj) dst[it] = -1;
+        AGX_STAMP(1);
         // the phase-2 tables are requested AFTER the frame pieces (vmcnt retires in order, so waiting
         // for them later costs nothing) and parked in LDS once the luminance work is done
         const int4 yt_own = p.ytab[dy0 + min(tid, rows - 1)];
@@ -264,49 +300,216 @@ __global__ __launch_bounds__(T) void k_ingest(IngestParams p) {
         if (tid < p.ow) xtab_s[tid] = xt_own;
         for (int i = tid + T; i < p.ow; i += T) xtab_s[i] = p.xtab[i];
     }
+    AGX_STAMP(2);
     __syncthreads();
+    AGX_STAMP(3);
 
     // phase 2: OpenCV fixed-point bilinear + max over the sampled frames
     if (tid < rows * ow4) {
         const int dyl = tid / ow4, xq = tid - dyl * ow4;
         const int dy = dy0 + dyl;
-        int b0 = 0, b1 = 0;
+        uint32_t b0 = 0, b1 = 0;
         int4 xt01 = make_int4(0, 0, 0, 0), xt23 = xt01;
         if (nvalid) {
             const int4 yt = ytab_s[dyl];
-            b0 = yt.z;
-            b1 = yt.w;
+            b0 = (uint32_t)yt.z;
+            b1 = (uint32_t)yt.w;
             xt01 = *reinterpret_cast<const int4 *>(xtab_s + xq * 4);
             xt23 = *reinterpret_cast<const int4 *>(xtab_s + xq * 4 + 2);
         }
         uint32_t packed = 0;
         const int xi[4] = {xt01.x, xt01.z, xt23.x, xt23.z};
         const int xa[4] = {xt01.y, xt01.w, xt23.y, xt23.w};
+        const unsigned char *row0 = gray + mul_u24((uint32_t)dyl, kRawW * 2);      // frame 0, this output row
+        const uint32_t fstride = (uint32_t)BR * kRawW * 2;                         // wave-uniform
 #if defined(AGX_ABL) && AGX_ABL == 12
-        packed = *reinterpret_cast<const uint32_t *>(gray + dyl * kRawW * 2 + xq * 4) + b0 + xi[0] + xa[3];
+        packed = *reinterpret_cast<const uint32_t *>(row0 + xq * 4) + b0 + xi[0] + xa[3];
 #else
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
-            const int x0 = xi[k] & 0xFFFF, x1 = xi[k] >> 16;
-            const int a0 = xa[k] & 0xFFFF, a1 = xa[k] >> 16;
-            int best = 0;
+            const uint32_t x0 = xi[k] & 0xFFFF, x1 = (uint32_t)xi[k] >> 16;
+            const uint32_t a0 = xa[k] & 0xFFFF, a1 = (uint32_t)xa[k] >> 16;
+            uint32_t best = 0;
             for (int f = 0; f < nvalid; ++f) {
-                const uint16_t *row = reinterpret_cast<const uint16_t *>(gray + (size_t)(f * BR + dyl) * kRawW * 2);
+                const uint16_t *row = reinterpret_cast<const uint16_t *>(row0 + f * fstride);
                 const uint32_t p0 = row[x0], p1 = row[x1];               // lo byte: row y0, hi byte: row y1
-                const int h0 = __mul24((int)(p0 & 0xFF), a0) + __mul24((int)(p1 & 0xFF), a1);
-                const int h1 = __mul24((int)(p0 >> 8), a0) + __mul24((int)(p1 >> 8), a1);
-                const int v = (((__mul24(b0, h0 >> 4) >> 16) + (__mul24(b1, h1 >> 4) >> 16) + 2) >> 2) & 0xFF;
+                const uint32_t h0 = mad_u24(p1 & 0xFF, a1, mul_u24(p0 & 0xFF, a0));
+                const uint32_t h1 = mad_u24(p1 >> 8, a1, mul_u24(p0 >> 8, a0));
+                const uint32_t v = (((mul_u24(b0, h0 >> 4) >> 16) + (mul_u24(b1, h1 >> 4) >> 16) + 2) >> 2) & 0xFF;
                 best = max(best, v);
             }
-            packed |= (uint32_t)best << (8 * k);
+            packed |= best << (8 * k);
         }
 #endif
-        const size_t fsz = (size_t)p.oh * p.ow;
-        uint8_t *env = p.ring + (size_t)n * p.fs * fsz;
-        const size_t off = (size_t)dy * p.ow + xq * 4;
-        *reinterpret_cast<uint32_t *>(env + slot * fsz + off) = packed;
+        const uint32_t fsz = (uint32_t)p.oh * p.ow;
+        uint8_t *env = p.ring + (size_t)n * p.fs * fsz;                            // wave-uniform
+        const uint32_t off = mad_u24((uint32_t)dy, (uint32_t)p.ow, (uint32_t)xq * 4);
+        *reinterpret_cast<uint32_t *>(env + (slot * fsz + off)) = packed;
         if (clear)
-            for (int s = 0; s < p.fs - 1; ++s) *reinterpret_cast<uint32_t *>(env + s * fsz + off) = 0u;
+            for (int s = 0; s < p.fs - 1; ++s) *reinterpret_cast<uint32_t *>(env + (s * fsz + off)) = 0u;
+    }
+    AGX_STAMP(4);
+}
+
+// ---------------------------------------------------------------------------------------------
+// K1, pipelined form: grid = (P, N), block = 256.  Workgroup (part, n) walks bands part, part+P, ...
+// of env n.  The NEXT band's source pieces are requested (registers B) before the current band's
+// luminance (registers A) is computed, so every wave has loads in flight for its whole life instead
+// of once per workgroup; gray bytes are double-buffered in LDS, one barrier per band.  All loads
+// are unconditional: the prefetch past the last band re-reads the last band (L2 hits, never used).
+// ---------------------------------------------------------------------------------------------
+template <int T>
+__global__ __launch_bounds__(T) void k_ingest_pipe(IngestParams p) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int n = blockIdx.y;
+    const int part = blockIdx.x, P = gridDim.x;
+    const int tid = threadIdx.x;
+    const uint32_t cmd = uniform_load_u8(p.cmd + n);
+    const int head = uniform_load_i32(p.head_in + n);
+    const bool skip = (cmd & AGX_CMD_SKIP) != 0;
+    const bool clear = (cmd & AGX_CMD_CLEAR) != 0;
+    if (part == 0 && tid == 0) p.head_out[n] = skip ? head : (clear ? 0 : (head + 1 == p.fs ? 0 : head + 1));
+    if (skip) return;
+    int nvalid = cmd & AGX_CMD_NVALID_MASK;
+    if (nvalid > 2) nvalid = 2;
+    const int slot = clear ? p.fs - 1 : head;
+
+    constexpr int G4 = kRawW / 4, RG = T / G4, kIter = 4;
+    const int BR = p.band_rows;
+    const int gray_bytes = 2 * BR * kRawW * 2;
+    int4 *ytab_s = reinterpret_cast<int4 *>(smem);                        // [oh]  {y0, y1, b0, b1}
+    int2 *xtab_s = reinterpret_cast<int2 *>(smem + sizeof(int4) * p.oh);    // [ow]
+    unsigned char *gray0 = smem + sizeof(int4) * p.oh + sizeof(int2) * p.ow;
+    unsigned char *gray1 = gray0 + gray_bytes;
+    for (int i = tid; i < p.oh; i += T) ytab_s[i] = p.ytab[i];
+    for (int i = tid; i < p.ow; i += T) xtab_s[i] = p.xtab[i];
+    const int ow4 = p.ow >> 2;
+    const int rg = tid / G4, g4 = tid - rg * G4;
+    const bool loader = rg < RG;
+    const uint8_t *fbase = p.frames + (size_t)n * 2 * kRawFrameBytes;
+    const uint32_t col = g4 * 12;
+    const size_t fsz = (size_t)p.oh * p.ow;
+    uint8_t *env = p.ring + (size_t)n * p.fs * fsz;
+    const int last_band = p.nbands - 1;
+    __syncthreads();
+
+    auto offsets = [&](int band, int it, uint32_t &o0, uint32_t &o1, int &d) {
+        const int dy0 = band * BR;
+        const int rows = min(BR, p.oh - dy0);
+        const int nrj = max(nvalid, 1) * rows;
+        const int rj_raw = rg + RG * it;
+        const int rj = min(rj_raw, nrj - 1);
+        const int f = rj >= rows ? 1 : 0;
+        const int dyl = rj - f * rows;
+        const int4 yt = ytab_s[dy0 + dyl];
+        const uint32_t fo = f * kRawFrameBytes + col;
+        o0 = mad_u24((uint32_t)yt.x, kRawRowBytes, fo);
+        o1 = mad_u24((uint32_t)yt.y, kRawRowBytes, fo);
+        d = (rj_raw < nvalid * rows && loader) ? ((f * BR + dyl) * kRawW + g4 * 4) * 2 : -1;
+    };
+    auto issue = [&](U3 (&w0)[kIter], U3 (&w1)[kIter], int band) {
+#pragma unroll
+        for (int it = 0; it < kIter; ++it) {
+            uint32_t o0, o1;
+            int d;
+            offsets(band, it, o0, o1, d);
+            w0[it] = *reinterpret_cast<const U3 *>(fbase + o0);
+            w1[it] = *reinterpret_cast<const U3 *>(fbase + o1);
+        }
+    };
+    auto lum_to_lds = [&](const U3 (&w0)[kIter], const U3 (&w1)[kIter], int band, unsigned char *gray) {
+        uint32_t tie_its = 0;
+#pragma unroll
+        for (int it = 0; it < kIter; ++it) {
+            bool tie = false;
+            const uint32_t top = lum4(w0[it].x, w0[it].y, w0[it].z, tie);
+            const uint32_t bot = lum4(w1[it].x, w1[it].y, w1[it].z, tie);
+            uint32_t o0, o1;
+            int d;
+            offsets(band, it, o0, o1, d);
+            if (d >= 0) {
+                uint2 v;
+                v.x = __builtin_amdgcn_perm(bot, top, 0x05010400u);
+                v.y = __builtin_amdgcn_perm(bot, top, 0x07030602u);
+                *reinterpret_cast<uint2 *>(gray + d) = v;
+                tie_its |= tie ? (1u << it) : 0u;
+            }
+        }
+        if (__builtin_expect(tie_its != 0, 0)) {
+#pragma nounroll
+            for (int it = 0; it < kIter; ++it) {
+                if (!((tie_its >> it) & 1u)) continue;
+                uint32_t o0, o1;
+                int d;
+                offsets(band, it, o0, o1, d);
+                const U3 a = *reinterpret_cast<const U3 *>(fbase + o0);
+                const U3 b = *reinterpret_cast<const U3 *>(fbase + o1);
+#pragma nounroll
+                for (int j = 0; j < 8; ++j) {
+                    const bool which = j & 1;
+                    const int k = j >> 1;
+                    const uint32_t x = which ? b.x : a.x, y = which ? b.y : a.y, z = which ? b.z : a.z;
+                    const uint64_t lo = (uint64_t)x | ((uint64_t)y << 32);
+                    const uint64_t hi = (uint64_t)y | ((uint64_t)z << 32);
+                    const uint32_t px = (uint32_t)(k < 2 ? (lo >> (24 * k)) : (hi >> (24 * k - 32)));
+                    gray[d + j] = (unsigned char)ale_lum_exact(px & 0xFF, (px >> 8) & 0xFF, (px >> 16) & 0xFF);
+                }
+            }
+        }
+    };
+    auto finish = [&](int band, const unsigned char *gray) {
+        const int dy0 = band * BR;
+        const int rows = min(BR, p.oh - dy0);
+        if (tid < rows * ow4) {
+            const int dyl = tid / ow4, xq = tid - dyl * ow4;
+            uint32_t packed = 0;
+            if (nvalid) {
+                const int4 yt = ytab_s[dy0 + dyl];
+                const int b0 = yt.z, b1 = yt.w;
+                const int4 xt01 = *reinterpret_cast<const int4 *>(xtab_s + xq * 4);
+                const int4 xt23 = *reinterpret_cast<const int4 *>(xtab_s + xq * 4 + 2);
+                const int xi[4] = {xt01.x, xt01.z, xt23.x, xt23.z};
+                const int xa[4] = {xt01.y, xt01.w, xt23.y, xt23.w};
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const int x0 = xi[k] & 0xFFFF, x1 = xi[k] >> 16;
+                    const int a0 = xa[k] & 0xFFFF, a1 = xa[k] >> 16;
+                    int best = 0;
+                    for (int f = 0; f < nvalid; ++f) {
+                        const uint16_t *row = reinterpret_cast<const uint16_t *>(gray + (size_t)(f * BR + dyl) * kRawW * 2);
+                        const uint32_t p0 = row[x0], p1 = row[x1];
+                        const uint32_t h0 = mad_u24(p1 & 0xFF, a1, mul_u24(p0 & 0xFF, a0));
+                        const uint32_t h1 = mad_u24(p1 >> 8, a1, mul_u24(p0 >> 8, a0));
+                        const int v = (int)((((mul_u24(b0, h0 >> 4) >> 16) + (mul_u24(b1, h1 >> 4) >> 16) + 2) >> 2) & 0xFF);
+                        best = max(best, v);
+                    }
+                    packed |= (uint32_t)best << (8 * k);
+                }
+            }
+            const size_t off = (size_t)(dy0 + dyl) * p.ow + xq * 4;
+            *reinterpret_cast<uint32_t *>(env + slot * fsz + off) = packed;
+            if (clear)
+                for (int s = 0; s < p.fs - 1; ++s) *reinterpret_cast<uint32_t *>(env + s * fsz + off) = 0u;
+        }
+    };
+
+    U3 a0[kIter], a1[kIter], b0[kIter], b1[kIter];
+    int band = part;
+    if (band > last_band) return;
+    issue(a0, a1, band);
+    while (true) {
+        issue(b0, b1, min(band + P, last_band));
+        lum_to_lds(a0, a1, band, gray0);
+        __syncthreads();
+        finish(band, gray0);
+        band += P;
+        if (band > last_band) break;
+        issue(a0, a1, min(band + P, last_band));
+        lum_to_lds(b0, b1, band, gray1);
+        __syncthreads();
+        finish(band, gray1);
+        band += P;
+        if (band > last_band) break;
     }
 }
 
