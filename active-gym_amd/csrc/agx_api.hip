@@ -29,6 +29,9 @@ struct agx_ctx {
     int4 *in_ytab = nullptr;
     Tap *fx_xtab = nullptr;    // K2 tables
     Tap *fx_ytab = nullptr;
+    int2 *per_ln[4] = {nullptr, nullptr, nullptr, nullptr};   // K3 tables
+    float *per_w[4] = {nullptr, nullptr, nullptr, nullptr};
+    int per_maxt[4] = {0, 0, 0, 0};
     int band_rows = 0;
     int ingest_t = 256;
     int rows_touched = 0;
@@ -102,6 +105,62 @@ void cv_axis(int src, int dst, bool is_x, std::vector<int> &i0, std::vector<int>
     }
 }
 
+// One axis of torchvision Resize (ATen upsample_bilinear2d, align_corners=False) as explicit taps:
+// antialiased triangle filter when down-scaling with antialias on (_compute_indices_min_size_weights_aa),
+// plain bilinear otherwise (area_pixel_compute_source_index); all in double, weights normalised.
+// compile-time tap bounds the tuned kernels are instantiated for (0 = run-time loops)
+int tap_bucket(int n) { return n <= 2 ? 2 : n <= 4 ? 4 : n <= 8 ? 8 : n <= 12 ? 12 : n <= 16 ? 16 : n; }
+
+void axis_taps(int n_in, int n_out, bool antialias, std::vector<int2> &ln, std::vector<float> &w, int &maxt) {
+    std::vector<std::vector<double>> ws(n_out);
+    ln.resize(n_out);
+    const double scale = (double)n_in / (double)n_out;
+    const bool aa = antialias && n_in > n_out;
+    maxt = 1;
+    for (int i = 0; i < n_out; ++i) {
+        if (aa) {
+            const double support = scale, invscale = 1.0 / scale, center = scale * (i + 0.5);
+            long long xmin = (long long)(center - support + 0.5);
+            if (xmin < 0) xmin = 0;
+            long long xmax = (long long)(center + support + 0.5);
+            if (xmax > n_in) xmax = n_in;
+            double total = 0.0;
+            for (long long jx = xmin; jx < xmax; ++jx) {
+                double x = ((double)jx - center + 0.5) * invscale;
+                if (x < 0) x = -x;
+                const double wv = x < 1.0 ? 1.0 - x : 0.0;
+                ws[i].push_back(wv);
+                total += wv;
+            }
+            if (total != 0.0)
+                for (double &v : ws[i]) v /= total;
+            ln[i] = make_int2((int)xmin, (int)ws[i].size());
+        } else {
+            double f = scale * (i + 0.5) - 0.5;
+            if (f < 0.0) f = 0.0;
+            int i0 = (int)f;
+            if (i0 > n_in - 1) i0 = n_in - 1;
+            const int i1 = i0 + (i0 < n_in - 1 ? 1 : 0);
+            const double l1 = f - i0;
+            if (i1 == i0) ws[i] = {1.0};              // (1-l)*p + l*p
+            else ws[i] = {1.0 - l1, l1};
+            ln[i] = make_int2(i0, (int)ws[i].size());
+        }
+        maxt = std::max(maxt, (int)ws[i].size());
+    }
+    maxt = tap_bucket(maxt);                          // zero-padded to the kernels' compile-time bounds
+    w.assign((size_t)n_out * maxt, 0.f);
+    for (int i = 0; i < n_out; ++i)
+        for (size_t k = 0; k < ws[i].size(); ++k) w[(size_t)i * maxt + k] = (float)ws[i][k];
+}
+
+size_t per2_lds(const agx_config &c) {
+    const size_t raw = ((size_t)c.obs_h * c.obs_w + 15) & ~(size_t)15;
+    size_t ab = (size_t)c.obs_h * c.per_w + (size_t)c.per_h * c.per_w;
+    ab = (ab + 3) & ~(size_t)3;                      // keep C 16-byte aligned
+    return 1024 + raw + (ab + (size_t)c.per_h * c.obs_w) * sizeof(float);
+}
+
 template <class T>
 int upload(agx_ctx *ctx, T **dptr, const std::vector<T> &h) {
     AGX_HIP(ctx, hipMalloc(reinterpret_cast<void **>(dptr), h.size() * sizeof(T)));
@@ -149,7 +208,9 @@ int agx_destroy(agx_ctx *ctx) {
     if (!ctx) return AGX_OK;
     DeviceGuard g(ctx->cfg.device);
     void *ptrs[] = {ctx->ring, ctx->head[0], ctx->head[1], ctx->loc[0], ctx->loc[1], ctx->res[0], ctx->res[1],
-                    ctx->in_xtab, ctx->in_ytab, ctx->fx_xtab, ctx->fx_ytab};
+                    ctx->in_xtab, ctx->in_ytab, ctx->fx_xtab, ctx->fx_ytab,
+                    ctx->per_ln[0], ctx->per_ln[1], ctx->per_ln[2], ctx->per_ln[3],
+                    ctx->per_w[0], ctx->per_w[1], ctx->per_w[2], ctx->per_w[3]};
     for (void *p : ptrs)
         if (p) (void)hipFree(p);
     delete ctx;
@@ -185,7 +246,8 @@ int agx_create(const agx_config *cfg, agx_ctx **out) {
             return fail(nullptr, AGX_E_INVALID, "fov_init_loc must be finite");
         if (c.kind == AGX_KIND_PERIPHERAL && (c.per_h < 1 || c.per_w < 1 || c.per_h > 1024 || c.per_w > 1024))
             return fail(nullptr, AGX_E_INVALID, "peripheral_res (%d,%d) out of range", c.per_h, c.per_w);
-        const size_t lds = c.kind == AGX_KIND_FIXED ? fixed_lds(c) : generic_lds(c);
+        const size_t lds = c.kind == AGX_KIND_FIXED ? fixed_lds(c)
+                           : (c.kind == AGX_KIND_PERIPHERAL ? std::min(per2_lds(c), generic_lds(c)) : generic_lds(c));
         if (lds > kMaxLds)
             return fail(nullptr, AGX_E_INVALID, "geometry needs %zu B of LDS per workgroup (limit %zu)", lds, kMaxLds);
     }
@@ -281,6 +343,19 @@ int agx_create(const agx_config *cfg, agx_ctx **out) {
         for (int b = 0; b < 2; ++b) {
             if ((rc = upload(ctx, &ctx->loc[b], loc)) != AGX_OK) return bail(rc);
             if ((rc = upload(ctx, &ctx->res[b], res)) != AGX_OK) return bail(rc);
+        }
+        if (c.kind == AGX_KIND_PERIPHERAL) {
+            const int nin[4] = {c.obs_w, c.obs_h, c.per_w, c.per_h};
+            const int nout[4] = {c.per_w, c.per_h, c.obs_w, c.obs_h};
+            for (int k = 0; k < 4; ++k) {
+                std::vector<int2> ln;
+                std::vector<float> w;
+                axis_taps(nin[k], nout[k], c.antialias != 0, ln, w, ctx->per_maxt[k]);
+                if (k == 0)                          // the first pass reads u8 numerators: fold the /255 into its weights
+                    for (float &v : w) v = (float)((double)v / 255.0);
+                if ((rc = upload(ctx, &ctx->per_ln[k], ln)) != AGX_OK) return bail(rc);
+                if ((rc = upload(ctx, &ctx->per_w[k], w)) != AGX_OK) return bail(rc);
+            }
         }
         if (c.kind == AGX_KIND_FIXED && c.out_mode == AGX_OUT_RESIZE) {
             std::vector<Tap> xt(c.obs_w), yt(c.obs_h);
@@ -558,8 +633,33 @@ int agx_fovea_peripheral(agx_ctx *ctx, const void *d_action, int action_dtype, c
     DeviceGuard g(c.device);
     const FovParams p = fov_params(ctx, d_action, action_dtype, nullptr, d_mask, d_obs, d_fov_loc, nullptr);
     const GeomR gr{c.obs_h, c.obs_w, c.fov_h, c.fov_w};
-    hipLaunchKernelGGL((k_fovea_generic<AGX_KIND_PERIPHERAL>), dim3(c.frame_stack, c.num_envs), dim3(kThreads),
-                       generic_lds(c), S(stream), gr, p);
+    static const bool generic_only = getenv("AGX_FOVEA_GENERIC") != nullptr;       // tuning / testing knob
+    // the tuned kernel keeps A | B | C with C 16-byte aligned and one row sweep per 256 threads
+    if (!generic_only && per2_lds(c) <= kMaxLds && c.per_w <= kThreads) {
+        PerParams g;
+        for (int k = 0; k < 4; ++k) {
+            g.t[k].ln = ctx->per_ln[k];
+            g.t[k].w = ctx->per_w[k];
+            g.t[k].maxt = ctx->per_maxt[k];
+        }
+        g.t[0].n_out = c.per_w; g.t[1].n_out = c.per_h; g.t[2].n_out = c.obs_w; g.t[3].n_out = c.obs_h;
+        g.oh = c.obs_h; g.ow = c.obs_w; g.fh = c.fov_h; g.fw = c.fov_w; g.ph = c.per_h; g.pw = c.per_w;
+        g.same = (c.per_h == c.obs_h && c.per_w == c.obs_w) ? 1 : 0;                // torchvision returns the input
+        const int mt = std::max(ctx->per_maxt[0], ctx->per_maxt[1]);
+        const dim3 grid(c.frame_stack, c.num_envs), block(kThreads);
+        const size_t lds = per2_lds(c);
+        // both squeeze tables are padded to their own bucket; the kernel bound must not exceed either row pitch
+        const bool same_bucket = ctx->per_maxt[0] == ctx->per_maxt[1];
+        if (same_bucket && mt == 2) hipLaunchKernelGGL(k_fovea_peripheral2<2>, grid, block, lds, S(stream), g, p);
+        else if (same_bucket && mt == 4) hipLaunchKernelGGL(k_fovea_peripheral2<4>, grid, block, lds, S(stream), g, p);
+        else if (same_bucket && mt == 8) hipLaunchKernelGGL(k_fovea_peripheral2<8>, grid, block, lds, S(stream), g, p);
+        else if (same_bucket && mt == 12) hipLaunchKernelGGL(k_fovea_peripheral2<12>, grid, block, lds, S(stream), g, p);
+        else if (same_bucket && mt == 16) hipLaunchKernelGGL(k_fovea_peripheral2<16>, grid, block, lds, S(stream), g, p);
+        else hipLaunchKernelGGL(k_fovea_peripheral2<0>, grid, block, lds, S(stream), g, p);
+    } else {
+        hipLaunchKernelGGL((k_fovea_generic<AGX_KIND_PERIPHERAL>), dim3(c.frame_stack, c.num_envs), dim3(kThreads),
+                           generic_lds(c), S(stream), gr, p);
+    }
     AGX_HIP(ctx, hipGetLastError());
     ctx->cur_fov ^= 1;
     return AGX_OK;

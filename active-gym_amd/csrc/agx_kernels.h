@@ -1099,6 +1099,203 @@ __global__ __launch_bounds__(kThreads) void k_fovea_generic(GeomR g, FovParams p
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// K3, tuned form: FixedFovealPeripheralEnv with the context's fixed geometry.
+// grid = (fs, N): workgroup (sl, n) owns physical ring slot sl; block = 256.
+// The four separable passes use tap tables built on the HOST at agx_create (ATen's arithmetic in
+// double, weights normalised, narrowed to f32): per output index {lo, n} and n weights.
+//   raw u8 frame --W squeeze--> A[oh][pw] --H squeeze--> B[ph][pw] --W expand--> C[ph][ow]
+//   --H expand, fused with the full-resolution fovea paste and the nontemporal store.
+// u8 -> f32 through the 256-entry LDS table.  ~27 KB LDS for 84/20: 5 workgroups per CU
+// (the generic kernel it replaces needed 43 KB and built its taps in f64 on the device).
+// ---------------------------------------------------------------------------------------------
+struct AxisTab {            // device pointers, one per pass
+    const int2 *ln;         // [n_out] {lo, n}
+    const float *w;         // [n_out][maxt]
+    int32_t n_out, maxt;
+};
+struct PerParams {
+    AxisTab t[4];           // 0: W squeeze (ow->pw), 1: H squeeze (oh->ph), 2: W expand (pw->ow), 3: H expand (ph->oh)
+    int32_t oh, ow, fh, fw, ph, pw, same;
+};
+
+// MT = compile-time bound of the squeeze passes' tap count (tables are zero-padded to it by the host);
+// MT == 0 keeps run-time trip counts.  With a fixed bound every LDS read of an output is issued before
+// the first FMA instead of one dependent read pair per tap.
+template <int MT>
+__global__ __launch_bounds__(kThreads) void k_fovea_peripheral2(PerParams g, FovParams p) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int sl = blockIdx.x, n = blockIdx.y, tid = threadIdx.x;
+    const int oh = g.oh, ow = g.ow, fh = g.fh, fw = g.fw, ph = g.ph, pw = g.pw;
+    if (p.mask && !p.mask[n]) {
+        if (sl == 0 && tid < 2) p.loc_out[2 * n + tid] = p.loc_in[2 * n + tid];
+        return;
+    }
+    const int fbytes = oh * ow, fwords = fbytes >> 2;
+    float *lut = reinterpret_cast<float *>(smem);                                  // [256]
+    unsigned char *raw = smem + 1024;                                              // [oh*ow]
+    float *A = reinterpret_cast<float *>(raw + ((fbytes + 15) & ~15));             // [oh][pw]
+    float *B = A + oh * pw;                                                        // [ph][pw]
+    float *C = A + ((oh * pw + ph * pw + 3) & ~3);                                 // [ph][ow], 16-B aligned (as per2_lds)
+    // ---- all round trips start now
+    const uint32_t *fsrc = reinterpret_cast<const uint32_t *>(p.ring + ((size_t)n * p.fs + sl) * (size_t)fbytes);
+    constexpr int kFW = 7;
+    uint32_t fw_[kFW];
+#pragma unroll
+    for (int k = 0; k < kFW; ++k) fw_[k] = fsrc[min(tid + k * kThreads, fwords - 1)];
+    const LocIn lin = load_loc_inputs(p, n);
+    const int head = p.head[n];
+    lut[tid] = unit((uint32_t)tid);
+    int r, c;
+    compute_loc(p, lin, oh - fh, ow - fw, r, c);
+    int j = sl - head;
+    if (j < 0) j += p.fs;
+    if (sl == 0 && tid == 0) {
+        p.loc_out[2 * n] = r;
+        p.loc_out[2 * n + 1] = c;
+        if (p.user_loc) {
+            p.user_loc[2 * n] = r;
+            p.user_loc[2 * n + 1] = c;
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < kFW; ++k)
+        if (tid + k * kThreads < fwords) reinterpret_cast<uint32_t *>(raw)[tid + k * kThreads] = fw_[k];
+    for (int i = tid + kFW * kThreads; i < fwords; i += kThreads) reinterpret_cast<uint32_t *>(raw)[i] = fsrc[i];
+    __syncthreads();
+
+    const int ow4 = ow >> 2;
+    float4 *out4 = reinterpret_cast<float4 *>(p.obs) + ((size_t)n * p.fs + j) * (size_t)(oh * ow4);
+    if (!g.same) {
+        // pass 0: A[y][xp] = sum_k w0[xp][k] * lut[raw[y][lo + k]]        (thread keeps column xp)
+        {
+            const AxisTab &t = g.t[0];
+            const int per = kThreads / pw;                       // rows per sweep
+            const int xp = tid % pw, y0 = tid / pw;
+            if (y0 < per) {
+                const int2 ln = t.ln[xp];
+                const float *w = t.w + xp * t.maxt;
+                // the pass-0 weights carry the 1/255 (host side), so bytes convert with v_cvt_f32_ubyteN and
+                // no table lookup: sum_k (w_k/255) * b_k differs from sum_k w_k * f32(b_k/255) by < 1e-7,
+                // far inside the 1e-5 bar of the float resize path (the pasted fovea keeps the exact table)
+                if (MT > 0) {
+                    constexpr int NDW = ((MT > 0 ? MT : 4) + 6) / 4;         // aligned dwords covering (lo & 3) + MT bytes
+                    float wr[MT > 0 ? MT : 1];
+#pragma unroll
+                    for (int k = 0; k < MT; ++k) wr[k] = w[k];
+                    for (int y = y0; y < oh; y += per) {
+                        const int off = y * ow + ln.x;
+                        const uint32_t *src = reinterpret_cast<const uint32_t *>(raw + (off & ~3));
+                        const uint32_t sh = off & 3;
+                        uint32_t d[NDW];
+#pragma unroll
+                        for (int k = 0; k < NDW; ++k) d[k] = src[k];         // reads past n hit zero weights
+                        float acc = 0.f;
+#pragma unroll
+                        for (int q4 = 0; q4 < MT / 4; ++q4) {
+                            const uint32_t v = __builtin_amdgcn_alignbyte(d[q4 + 1], d[q4], sh);
+                            acc = fmaf(wr[4 * q4 + 0], (float)(v & 0xFF), acc);
+                            acc = fmaf(wr[4 * q4 + 1], (float)((v >> 8) & 0xFF), acc);
+                            acc = fmaf(wr[4 * q4 + 2], (float)((v >> 16) & 0xFF), acc);
+                            acc = fmaf(wr[4 * q4 + 3], (float)(v >> 24), acc);
+                        }
+                        if (MT % 4) {
+                            const uint32_t v = __builtin_amdgcn_alignbyte(d[MT / 4 + 1], d[MT / 4], sh);
+#pragma unroll
+                            for (int k = 0; k < MT % 4; ++k) acc = fmaf(wr[(MT / 4) * 4 + k], (float)((v >> (8 * k)) & 0xFF), acc);
+                        }
+                        A[y * pw + xp] = acc;
+                    }
+                } else {
+                    for (int y = y0; y < oh; y += per) {
+                        const unsigned char *src = raw + y * ow + ln.x;
+                        float acc = 0.f;
+                        for (int k = 0; k < ln.y; ++k) acc = fmaf(w[k], (float)src[k], acc);
+                        A[y * pw + xp] = acc;
+                    }
+                }
+            }
+        }
+        __syncthreads();
+        // pass 1: B[yp][xp] = sum_k w1[yp][k] * A[lo + k][xp]
+        {
+            const AxisTab &t = g.t[1];
+            for (int i = tid; i < ph * pw; i += kThreads) {
+                const int yp = i / pw, xp = i - yp * pw;
+                const int2 ln = t.ln[yp];
+                const float *w = t.w + yp * t.maxt;
+                float acc = 0.f;
+                if (MT > 0) {
+                    float v[MT > 0 ? MT : 1];
+#pragma unroll
+                    for (int k = 0; k < MT; ++k) v[k] = A[min(ln.x + k, oh - 1) * pw + xp];   // clamped: weight is 0 there
+#pragma unroll
+                    for (int k = 0; k < MT; ++k) acc = fmaf(w[k], v[k], acc);
+                } else {
+                    for (int k = 0; k < ln.y; ++k) acc = fmaf(w[k], A[(ln.x + k) * pw + xp], acc);
+                }
+                B[i] = acc;
+            }
+        }
+        __syncthreads();
+        // pass 2: C[yp][x] = sum_k w2[x][k] * B[yp][lo + k]               (thread keeps column x)
+        {
+            const AxisTab &t = g.t[2];
+            const int per = kThreads / ow;
+            if (per > 0) {
+                const int x = tid % ow, y0 = tid / ow;
+                if (y0 < per) {
+                    const int2 ln = t.ln[x];
+                    const float *w = t.w + x * t.maxt;
+                    for (int yp = y0; yp < ph; yp += per) {
+                        float acc = 0.f;
+                        for (int k = 0; k < ln.y; ++k) acc = fmaf(w[k], B[yp * pw + ln.x + k], acc);
+                        C[yp * ow + x] = acc;
+                    }
+                }
+            } else {
+                for (int i = tid; i < ph * ow; i += kThreads) {
+                    const int yp = i / ow, x = i - yp * ow;
+                    const int2 ln = t.ln[x];
+                    const float *w = t.w + x * t.maxt;
+                    float acc = 0.f;
+                    for (int k = 0; k < ln.y; ++k) acc = fmaf(w[k], B[yp * pw + ln.x + k], acc);
+                    C[i] = acc;
+                }
+            }
+        }
+        __syncthreads();
+    }
+    // pass 3 fused with paste + store: out[row][x..x+3]
+    const AxisTab &t3 = g.t[3];
+    const float4 *C4 = reinterpret_cast<const float4 *>(C);
+    for (int q = tid; q < oh * ow4; q += kThreads) {
+        const int row = q / ow4, x4 = q - row * ow4, x = x4 * 4;
+        float4 o = make_float4(0.f, 0.f, 0.f, 0.f);
+        const bool in_r = row >= r && row < r + fh;
+        const bool all_fov = g.same || (in_r && x >= c && x + 3 < c + fw);
+        if (!all_fov) {
+            const int2 ln = t3.ln[row];
+            const float *w = t3.w + row * t3.maxt;
+            for (int k = 0; k < ln.y; ++k) {
+                const float4 v = C4[(ln.x + k) * ow4 + x4];
+                o.x = fmaf(w[k], v.x, o.x);
+                o.y = fmaf(w[k], v.y, o.y);
+                o.z = fmaf(w[k], v.z, o.z);
+                o.w = fmaf(w[k], v.w, o.w);
+            }
+        }
+        if (g.same || (in_r && x + 3 >= c && x < c + fw)) {
+            const uint32_t wv = *reinterpret_cast<const uint32_t *>(raw + row * ow + x);
+            if (g.same || (x >= c && x < c + fw)) o.x = lut[wv & 0xFF];
+            if (g.same || (x + 1 >= c && x + 1 < c + fw)) o.y = lut[(wv >> 8) & 0xFF];
+            if (g.same || (x + 2 >= c && x + 2 < c + fw)) o.z = lut[(wv >> 16) & 0xFF];
+            if (g.same || (x + 3 >= c && x + 3 < c + fw)) o.w = lut[wv >> 24];
+        }
+        store_obs(&out4[q], o);
+    }
+}
+
 // fov_loc / fov_res (re)initialisation for masked envs (fov_env.py:149-150,250-251)
 struct FovResetParams {
     const uint8_t *mask;
