@@ -154,11 +154,22 @@ void axis_taps(int n_in, int n_out, bool antialias, std::vector<int2> &ln, std::
         for (size_t k = 0; k < ws[i].size(); ++k) w[(size_t)i * maxt + k] = (float)ws[i][k];
 }
 
+size_t per2_tables(const agx_config &c) {
+    std::vector<int2> ln;
+    std::vector<float> w;
+    int m1 = 0, m3 = 0;
+    axis_taps(c.obs_h, c.per_h, c.antialias != 0, ln, w, m1);
+    axis_taps(c.per_h, c.obs_h, c.antialias != 0, ln, w, m3);
+    return (size_t)c.per_h * (sizeof(int2) + m1 * sizeof(float)) + (size_t)c.obs_h * (sizeof(int2) + m3 * sizeof(float));
+}
+
 size_t per2_lds(const agx_config &c) {
     const size_t raw = ((size_t)c.obs_h * c.obs_w + 15) & ~(size_t)15;
     size_t ab = (size_t)c.obs_h * c.per_w + (size_t)c.per_h * c.per_w;
     ab = (ab + 3) & ~(size_t)3;                      // keep C 16-byte aligned
-    return 1024 + raw + (ab + (size_t)c.per_h * c.obs_w) * sizeof(float);
+    // + the pass-1 and pass-3 tap tables ({lo,n} + zero-padded weights; bounded by the bucketed tap counts,
+    //   which per2_tables() below computes the same way agx_create does)
+    return 1024 + raw + (ab + (size_t)c.per_h * c.obs_w) * sizeof(float) + per2_tables(c);
 }
 
 template <class T>

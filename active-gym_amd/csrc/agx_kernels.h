@@ -1131,18 +1131,42 @@ __global__ __launch_bounds__(kThreads) void k_fovea_peripheral2(PerParams g, Fov
         if (sl == 0 && tid < 2) p.loc_out[2 * n + tid] = p.loc_in[2 * n + tid];
         return;
     }
+    constexpr int MTR = MT > 0 ? MT : 1;
     const int fbytes = oh * ow, fwords = fbytes >> 2;
-    float *lut = reinterpret_cast<float *>(smem);                                  // [256]
-    unsigned char *raw = smem + 1024;                                              // [oh*ow]
-    float *A = reinterpret_cast<float *>(raw + ((fbytes + 15) & ~15));             // [oh][pw]
-    float *B = A + oh * pw;                                                        // [ph][pw]
-    float *C = A + ((oh * pw + ph * pw + 3) & ~3);                                 // [ph][ow], 16-B aligned (as per2_lds)
-    // ---- all round trips start now
+    const int mt1 = g.t[1].maxt, mt3 = g.t[3].maxt;
+    // LDS: lut[256] | raw[oh*ow] | A[oh][pw] | B[ph][pw] | C[ph][ow] | pass-1 table | pass-3 table
+    float *lut = reinterpret_cast<float *>(smem);
+    unsigned char *raw = smem + 1024;
+    float *A = reinterpret_cast<float *>(raw + ((fbytes + 15) & ~15));
+    float *B = A + oh * pw;
+    float *C = A + ((oh * pw + ph * pw + 3) & ~3);                                 // 16-B aligned (as per2_lds)
+    int2 *ln1_s = reinterpret_cast<int2 *>(C + ph * ow);                           // [ph]
+    float *w1_s = reinterpret_cast<float *>(ln1_s + ph);                           // [ph][mt1]
+    int2 *ln3_s = reinterpret_cast<int2 *>(w1_s + ph * mt1);                       // [oh]
+    float *w3_s = reinterpret_cast<float *>(ln3_s + oh);                           // [oh][mt3]
+
+    // ---- every round trip starts now: the frame, this thread's pass-0 / pass-2 taps (registers), the
+    // pass-1 / pass-3 tables (-> LDS), then the small state loads
     const uint32_t *fsrc = reinterpret_cast<const uint32_t *>(p.ring + ((size_t)n * p.fs + sl) * (size_t)fbytes);
     constexpr int kFW = 7;
     uint32_t fw_[kFW];
 #pragma unroll
     for (int k = 0; k < kFW; ++k) fw_[k] = fsrc[min(tid + k * kThreads, fwords - 1)];
+    const int xp0 = tid % pw, y00 = tid / pw, per0 = kThreads / pw;                // pass 0: column xp0, rows y00 + per0*i
+    const int2 ln0 = g.t[0].ln[xp0];
+    float wr0[MTR];
+    if (MT > 0) {
+#pragma unroll
+        for (int k = 0; k < MT; ++k) wr0[k] = g.t[0].w[xp0 * g.t[0].maxt + k];
+    }
+    const int per2 = kThreads / ow;                                                // pass 2: column x2, rows y20 + per2*i
+    const int x2 = per2 > 0 ? tid % ow : 0, y20 = per2 > 0 ? tid / ow : 0;
+    const int2 ln2 = g.t[2].ln[x2];
+    const float w2a = g.t[2].w[x2 * g.t[2].maxt], w2b = g.t[2].maxt > 1 ? g.t[2].w[x2 * g.t[2].maxt + 1] : 0.f;
+    for (int i = tid; i < ph; i += kThreads) ln1_s[i] = g.t[1].ln[i];
+    for (int i = tid; i < ph * mt1; i += kThreads) w1_s[i] = g.t[1].w[i];
+    for (int i = tid; i < oh; i += kThreads) ln3_s[i] = g.t[3].ln[i];
+    for (int i = tid; i < oh * mt3; i += kThreads) w3_s[i] = g.t[3].w[i];
     const LocIn lin = load_loc_inputs(p, n);
     const int head = p.head[n];
     lut[tid] = unit((uint32_t)tid);
@@ -1167,107 +1191,86 @@ __global__ __launch_bounds__(kThreads) void k_fovea_peripheral2(PerParams g, Fov
     const int ow4 = ow >> 2;
     float4 *out4 = reinterpret_cast<float4 *>(p.obs) + ((size_t)n * p.fs + j) * (size_t)(oh * ow4);
     if (!g.same) {
-        // pass 0: A[y][xp] = sum_k w0[xp][k] * lut[raw[y][lo + k]]        (thread keeps column xp)
-        {
-            const AxisTab &t = g.t[0];
-            const int per = kThreads / pw;                       // rows per sweep
-            const int xp = tid % pw, y0 = tid / pw;
-            if (y0 < per) {
-                const int2 ln = t.ln[xp];
-                const float *w = t.w + xp * t.maxt;
-                // the pass-0 weights carry the 1/255 (host side), so bytes convert with v_cvt_f32_ubyteN and
-                // no table lookup: sum_k (w_k/255) * b_k differs from sum_k w_k * f32(b_k/255) by < 1e-7,
-                // far inside the 1e-5 bar of the float resize path (the pasted fovea keeps the exact table)
-                if (MT > 0) {
-                    constexpr int NDW = ((MT > 0 ? MT : 4) + 6) / 4;         // aligned dwords covering (lo & 3) + MT bytes
-                    float wr[MT > 0 ? MT : 1];
+        // pass 0: A[y][xp] = sum_k (w0[xp][k] / 255) * raw[y][lo + k]
+        // The pass-0 weights carry the 1/255 (host side), so bytes convert with v_cvt_f32_ubyteN and no
+        // table lookup: sum_k (w_k/255) * b_k differs from sum_k w_k * f32(b_k/255) by < 1e-7, far inside
+        // the 1e-5 bar of the float resize path (the pasted fovea keeps the exact table).
+        if (y00 < per0) {
+            if (MT > 0) {
+                constexpr int NDW = (MTR + 6) / 4;                   // aligned dwords covering (lo & 3) + MT bytes
+                for (int y = y00; y < oh; y += per0) {
+                    const int off = y * ow + ln0.x;
+                    const uint32_t *src = reinterpret_cast<const uint32_t *>(raw + (off & ~3));
+                    const uint32_t sh = off & 3;
+                    uint32_t d[NDW];
 #pragma unroll
-                    for (int k = 0; k < MT; ++k) wr[k] = w[k];
-                    for (int y = y0; y < oh; y += per) {
-                        const int off = y * ow + ln.x;
-                        const uint32_t *src = reinterpret_cast<const uint32_t *>(raw + (off & ~3));
-                        const uint32_t sh = off & 3;
-                        uint32_t d[NDW];
+                    for (int k = 0; k < NDW; ++k) d[k] = src[k];     // reads past n hit zero weights
+                    float acc = 0.f;
 #pragma unroll
-                        for (int k = 0; k < NDW; ++k) d[k] = src[k];         // reads past n hit zero weights
-                        float acc = 0.f;
-#pragma unroll
-                        for (int q4 = 0; q4 < MT / 4; ++q4) {
-                            const uint32_t v = __builtin_amdgcn_alignbyte(d[q4 + 1], d[q4], sh);
-                            acc = fmaf(wr[4 * q4 + 0], (float)(v & 0xFF), acc);
-                            acc = fmaf(wr[4 * q4 + 1], (float)((v >> 8) & 0xFF), acc);
-                            acc = fmaf(wr[4 * q4 + 2], (float)((v >> 16) & 0xFF), acc);
-                            acc = fmaf(wr[4 * q4 + 3], (float)(v >> 24), acc);
-                        }
-                        if (MT % 4) {
-                            const uint32_t v = __builtin_amdgcn_alignbyte(d[MT / 4 + 1], d[MT / 4], sh);
-#pragma unroll
-                            for (int k = 0; k < MT % 4; ++k) acc = fmaf(wr[(MT / 4) * 4 + k], (float)((v >> (8 * k)) & 0xFF), acc);
-                        }
-                        A[y * pw + xp] = acc;
+                    for (int q4 = 0; q4 < MT / 4; ++q4) {
+                        const uint32_t v = __builtin_amdgcn_alignbyte(d[q4 + 1], d[q4], sh);
+                        acc = fmaf(wr0[4 * q4 + 0], (float)(v & 0xFF), acc);
+                        acc = fmaf(wr0[4 * q4 + 1], (float)((v >> 8) & 0xFF), acc);
+                        acc = fmaf(wr0[4 * q4 + 2], (float)((v >> 16) & 0xFF), acc);
+                        acc = fmaf(wr0[4 * q4 + 3], (float)(v >> 24), acc);
                     }
-                } else {
-                    for (int y = y0; y < oh; y += per) {
-                        const unsigned char *src = raw + y * ow + ln.x;
-                        float acc = 0.f;
-                        for (int k = 0; k < ln.y; ++k) acc = fmaf(w[k], (float)src[k], acc);
-                        A[y * pw + xp] = acc;
+                    if (MT % 4) {
+                        const uint32_t v = __builtin_amdgcn_alignbyte(d[MT / 4 + 1], d[MT / 4], sh);
+#pragma unroll
+                        for (int k = 0; k < MT % 4; ++k) acc = fmaf(wr0[(MT / 4) * 4 + k], (float)((v >> (8 * k)) & 0xFF), acc);
                     }
+                    A[y * pw + xp0] = acc;
+                }
+            } else {
+                const float *w = g.t[0].w + xp0 * g.t[0].maxt;
+                for (int y = y00; y < oh; y += per0) {
+                    const unsigned char *src = raw + y * ow + ln0.x;
+                    float acc = 0.f;
+                    for (int k = 0; k < ln0.y; ++k) acc = fmaf(w[k], (float)src[k], acc);
+                    A[y * pw + xp0] = acc;
                 }
             }
         }
         __syncthreads();
         // pass 1: B[yp][xp] = sum_k w1[yp][k] * A[lo + k][xp]
-        {
-            const AxisTab &t = g.t[1];
-            for (int i = tid; i < ph * pw; i += kThreads) {
-                const int yp = i / pw, xp = i - yp * pw;
-                const int2 ln = t.ln[yp];
-                const float *w = t.w + yp * t.maxt;
-                float acc = 0.f;
-                if (MT > 0) {
-                    float v[MT > 0 ? MT : 1];
+        for (int i = tid; i < ph * pw; i += kThreads) {
+            const int yp = i / pw, xp = i - yp * pw;
+            const int2 ln = ln1_s[yp];
+            const float *w = w1_s + yp * mt1;
+            float acc = 0.f;
+            if (MT > 0) {
+                float v[MTR];
 #pragma unroll
-                    for (int k = 0; k < MT; ++k) v[k] = A[min(ln.x + k, oh - 1) * pw + xp];   // clamped: weight is 0 there
+                for (int k = 0; k < MT; ++k) v[k] = A[min(ln.x + k, oh - 1) * pw + xp];   // clamped: weight is 0 there
 #pragma unroll
-                    for (int k = 0; k < MT; ++k) acc = fmaf(w[k], v[k], acc);
-                } else {
-                    for (int k = 0; k < ln.y; ++k) acc = fmaf(w[k], A[(ln.x + k) * pw + xp], acc);
-                }
-                B[i] = acc;
+                for (int k = 0; k < MT; ++k) acc = fmaf(w[k], v[k], acc);
+            } else {
+                for (int k = 0; k < ln.y; ++k) acc = fmaf(w[k], A[(ln.x + k) * pw + xp], acc);
             }
+            B[i] = acc;
         }
         __syncthreads();
-        // pass 2: C[yp][x] = sum_k w2[x][k] * B[yp][lo + k]               (thread keeps column x)
-        {
+        // pass 2: C[yp][x] = sum_k w2[x][k] * B[yp][lo + k]     (expansion: at most 2 taps when pw <= ow)
+        if (per2 > 0 && g.t[2].maxt <= 2) {
+            if (y20 < per2) {
+                const int i1 = ln2.y > 1 ? ln2.x + 1 : ln2.x;
+                for (int yp = y20; yp < ph; yp += per2)
+                    C[yp * ow + x2] = fmaf(w2b, B[yp * pw + i1], w2a * B[yp * pw + ln2.x]);
+            }
+        } else {
             const AxisTab &t = g.t[2];
-            const int per = kThreads / ow;
-            if (per > 0) {
-                const int x = tid % ow, y0 = tid / ow;
-                if (y0 < per) {
-                    const int2 ln = t.ln[x];
-                    const float *w = t.w + x * t.maxt;
-                    for (int yp = y0; yp < ph; yp += per) {
-                        float acc = 0.f;
-                        for (int k = 0; k < ln.y; ++k) acc = fmaf(w[k], B[yp * pw + ln.x + k], acc);
-                        C[yp * ow + x] = acc;
-                    }
-                }
-            } else {
-                for (int i = tid; i < ph * ow; i += kThreads) {
-                    const int yp = i / ow, x = i - yp * ow;
-                    const int2 ln = t.ln[x];
-                    const float *w = t.w + x * t.maxt;
-                    float acc = 0.f;
-                    for (int k = 0; k < ln.y; ++k) acc = fmaf(w[k], B[yp * pw + ln.x + k], acc);
-                    C[i] = acc;
-                }
+            for (int i = tid; i < ph * ow; i += kThreads) {
+                const int yp = i / ow, x = i - yp * ow;
+                const int2 ln = t.ln[x];
+                const float *w = t.w + x * t.maxt;
+                float acc = 0.f;
+                for (int k = 0; k < ln.y; ++k) acc = fmaf(w[k], B[yp * pw + ln.x + k], acc);
+                C[i] = acc;
             }
         }
         __syncthreads();
     }
     // pass 3 fused with paste + store: out[row][x..x+3]
-    const AxisTab &t3 = g.t[3];
     const float4 *C4 = reinterpret_cast<const float4 *>(C);
     for (int q = tid; q < oh * ow4; q += kThreads) {
         const int row = q / ow4, x4 = q - row * ow4, x = x4 * 4;
@@ -1275,8 +1278,8 @@ __global__ __launch_bounds__(kThreads) void k_fovea_peripheral2(PerParams g, Fov
         const bool in_r = row >= r && row < r + fh;
         const bool all_fov = g.same || (in_r && x >= c && x + 3 < c + fw);
         if (!all_fov) {
-            const int2 ln = t3.ln[row];
-            const float *w = t3.w + row * t3.maxt;
+            const int2 ln = ln3_s[row];
+            const float *w = w3_s + row * mt3;
             for (int k = 0; k < ln.y; ++k) {
                 const float4 v = C4[(ln.x + k) * ow4 + x4];
                 o.x = fmaf(w[k], v.x, o.x);
