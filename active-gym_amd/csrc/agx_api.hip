@@ -32,6 +32,11 @@ struct agx_ctx {
     int2 *per_ln[4] = {nullptr, nullptr, nullptr, nullptr};   // K3 tables
     float *per_w[4] = {nullptr, nullptr, nullptr, nullptr};
     int per_maxt[4] = {0, 0, 0, 0};
+    // K4 table families (wd, wb, wf, hd, hb, hf): entries, weights, per-size meta
+    int2 *flex_ln[6] = {};
+    float *flex_w[6] = {};
+    int4 *flex_meta[6] = {};
+    size_t flex_tab_floats = 0;   // worst-case LDS floats of the staged tables
     int band_rows = 0;
     int ingest_t = 256;
     int rows_touched = 0;
@@ -172,6 +177,41 @@ size_t per2_lds(const agx_config &c) {
     return 1024 + raw + (ab + (size_t)c.per_h * c.obs_w) * sizeof(float) + per2_tables(c);
 }
 
+// K4: one family = the taps of every window size r in [1, rmax] along one axis.
+//   which = 0: r -> fov (squeeze)   1: fov -> r (expand back)   2: r -> obs (final resize)
+struct HostFamily {
+    std::vector<int2> ln;
+    std::vector<float> w;
+    std::vector<int4> meta;                       // [rmax + 1]
+    std::vector<size_t> floats;                   // LDS floats of the staged table of size r
+};
+HostFamily build_family(int which, int rmax, int fov, int obs, bool antialias) {
+    HostFamily f;
+    f.meta.assign(rmax + 1, make_int4(0, 0, 1, 0));
+    f.floats.assign(rmax + 1, 0);
+    for (int r = 1; r <= rmax; ++r) {
+        std::vector<int2> ln;
+        std::vector<float> w;
+        int maxt = 0;
+        const int n_in = which == 0 ? r : (which == 1 ? fov : r);
+        const int n_out = which == 0 ? fov : (which == 1 ? r : obs);
+        axis_taps(n_in, n_out, antialias, ln, w, maxt);
+        f.meta[r] = make_int4((int)f.ln.size(), (int)f.w.size(), maxt, n_out);
+        f.floats[r] = (((size_t)2 * n_out + (size_t)n_out * maxt) + 3) & ~(size_t)3;
+        f.ln.insert(f.ln.end(), ln.begin(), ln.end());
+        f.w.insert(f.w.end(), w.begin(), w.end());
+    }
+    return f;
+}
+
+size_t flex2_lds(const agx_config &c, size_t tab_floats) {
+    const size_t raw = ((size_t)c.obs_h * c.obs_w + 15) & ~(size_t)15;
+    const size_t ae = (std::max((size_t)c.obs_h * c.fov_w, (size_t)c.fov_h * c.obs_w) + 3) & ~(size_t)3;
+    const size_t b = ((size_t)c.fov_h * c.fov_w + 3) & ~(size_t)3;
+    const size_t cc = ((size_t)c.fov_h * c.obs_w + 3) & ~(size_t)3;
+    return 1024 + raw + (ae + b + cc + tab_floats) * sizeof(float);
+}
+
 template <class T>
 int upload(agx_ctx *ctx, T **dptr, const std::vector<T> &h) {
     AGX_HIP(ctx, hipMalloc(reinterpret_cast<void **>(dptr), h.size() * sizeof(T)));
@@ -221,7 +261,11 @@ int agx_destroy(agx_ctx *ctx) {
     void *ptrs[] = {ctx->ring, ctx->head[0], ctx->head[1], ctx->loc[0], ctx->loc[1], ctx->res[0], ctx->res[1],
                     ctx->in_xtab, ctx->in_ytab, ctx->fx_xtab, ctx->fx_ytab,
                     ctx->per_ln[0], ctx->per_ln[1], ctx->per_ln[2], ctx->per_ln[3],
-                    ctx->per_w[0], ctx->per_w[1], ctx->per_w[2], ctx->per_w[3]};
+                    ctx->per_w[0], ctx->per_w[1], ctx->per_w[2], ctx->per_w[3],
+                    ctx->flex_ln[0], ctx->flex_ln[1], ctx->flex_ln[2], ctx->flex_ln[3], ctx->flex_ln[4], ctx->flex_ln[5],
+                    ctx->flex_w[0], ctx->flex_w[1], ctx->flex_w[2], ctx->flex_w[3], ctx->flex_w[4], ctx->flex_w[5],
+                    ctx->flex_meta[0], ctx->flex_meta[1], ctx->flex_meta[2], ctx->flex_meta[3], ctx->flex_meta[4],
+                    ctx->flex_meta[5]};
     for (void *p : ptrs)
         if (p) (void)hipFree(p);
     delete ctx;
@@ -354,6 +398,21 @@ int agx_create(const agx_config *cfg, agx_ctx **out) {
         for (int b = 0; b < 2; ++b) {
             if ((rc = upload(ctx, &ctx->loc[b], loc)) != AGX_OK) return bail(rc);
             if ((rc = upload(ctx, &ctx->res[b], res)) != AGX_OK) return bail(rc);
+        }
+        if (c.kind == AGX_KIND_FLEXIBLE) {
+            size_t worst_w = 0, worst_h = 0;
+            HostFamily fam[6];
+            for (int k = 0; k < 6; ++k) {
+                const bool is_w = k < 3;
+                fam[k] = build_family(k % 3, is_w ? c.obs_w : c.obs_h, is_w ? c.fov_w : c.fov_h, is_w ? c.obs_w : c.obs_h,
+                                      c.antialias != 0);
+                if ((rc = upload(ctx, &ctx->flex_ln[k], fam[k].ln)) != AGX_OK) return bail(rc);
+                if ((rc = upload(ctx, &ctx->flex_w[k], fam[k].w)) != AGX_OK) return bail(rc);
+                if ((rc = upload(ctx, &ctx->flex_meta[k], fam[k].meta)) != AGX_OK) return bail(rc);
+            }
+            for (int r = 1; r <= c.obs_w; ++r) worst_w = std::max(worst_w, fam[0].floats[r] + fam[1].floats[r] + fam[2].floats[r]);
+            for (int r = 1; r <= c.obs_h; ++r) worst_h = std::max(worst_h, fam[3].floats[r] + fam[4].floats[r] + fam[5].floats[r]);
+            ctx->flex_tab_floats = worst_w + worst_h;
         }
         if (c.kind == AGX_KIND_PERIPHERAL) {
             const int nin[4] = {c.obs_w, c.obs_h, c.per_w, c.per_h};
@@ -687,8 +746,22 @@ int agx_fovea_flexible(agx_ctx *ctx, const void *d_action, int action_dtype, con
     DeviceGuard g(c.device);
     const FovParams p = fov_params(ctx, d_action, action_dtype, d_action_type, d_mask, d_obs, d_fov_loc, d_fov_res);
     const GeomR gr{c.obs_h, c.obs_w, c.fov_h, c.fov_w};
-    hipLaunchKernelGGL((k_fovea_generic<AGX_KIND_FLEXIBLE>), dim3(c.frame_stack, c.num_envs), dim3(kThreads),
-                       generic_lds(c), S(stream), gr, p);
+    static const bool generic_only = getenv("AGX_FOVEA_GENERIC") != nullptr;       // tuning / testing knob
+    const size_t lds2 = flex2_lds(c, ctx->flex_tab_floats);
+    if (!generic_only && lds2 <= kMaxLds) {
+        FlexParams g;
+        TabFamily *fam[6] = {&g.wd, &g.wb, &g.wf, &g.hd, &g.hb, &g.hf};
+        for (int k = 0; k < 6; ++k) {
+            fam[k]->ln = ctx->flex_ln[k];
+            fam[k]->w = ctx->flex_w[k];
+            fam[k]->meta = ctx->flex_meta[k];
+        }
+        g.oh = c.obs_h; g.ow = c.obs_w; g.fh = c.fov_h; g.fw = c.fov_w;
+        hipLaunchKernelGGL(k_fovea_flexible2, dim3(c.frame_stack, c.num_envs), dim3(kThreads), lds2, S(stream), g, p);
+    } else {
+        hipLaunchKernelGGL((k_fovea_generic<AGX_KIND_FLEXIBLE>), dim3(c.frame_stack, c.num_envs), dim3(kThreads),
+                           generic_lds(c), S(stream), gr, p);
+    }
     AGX_HIP(ctx, hipGetLastError());
     ctx->cur_fov ^= 1;
     return AGX_OK;

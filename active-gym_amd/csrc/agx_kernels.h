@@ -1299,6 +1299,245 @@ __global__ __launch_bounds__(kThreads) void k_fovea_peripheral2(PerParams g, Fov
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// K4, tuned form: FlexibleFovealEnv (per-env ragged window rh x rw).  grid = (fs, N), block = 256,
+// workgroup (sl, n) owns physical ring slot sl.
+// Tap tables for every window size r come from the HOST (agx_create): per axis three families,
+//   dwn[r]: r -> fov (the squeeze, antialiased when r > fov and antialias is on)
+//   bck[r]: fov -> r (the expansion back; an antialiased DOWN-scale when r < fov)
+//   fin[r]: r -> obs (the final resize_to_full, always an up-scale)
+// The reference's chain  crop -> Resize(fov_size) -> Resize(fov_res) -> Resize(obs_size)
+// (fov_env.py:276-298) is evaluated without its two largest intermediates:
+//   A[rh][fw] = Wdwn(crop)   B[fh][fw] = Hdwn(A)   C[fh][rw] = Wbck(B)
+//   resize: E[fh][ow] = Wfin(C), out[y] = sum_a Hfin[y][a] * sum_b Hbck[i_a][b] * E[j_ab]   (H passes composed)
+//   mask / raw: out[y][x] = sum_b Hbck[y][b] * C[j_b][x]
+// (W and H passes act on different axes and commute; only float rounding differs, ~1e-7.)
+// ---------------------------------------------------------------------------------------------
+struct TabFamily {
+    const int2 *ln;      // {lo, n} entries of all sizes, concatenated
+    const float *w;      // weights, pitch meta[r].z per entry
+    const int4 *meta;    // [rmax + 1]: {first entry, first weight, maxt, entry count} of size r
+};
+struct FlexParams {
+    TabFamily wd, wb, wf, hd, hb, hf;
+    int32_t oh, ow, fh, fw;
+};
+
+struct LdsTab {          // one staged table
+    const int2 *ln;
+    const float *w;
+    int maxt;
+};
+// copy the table of size r into LDS at float offset `off` (kept a multiple of 4 floats)
+__device__ __forceinline__ LdsTab stage_tab(const TabFamily &f, int r, float *base, int &off, int tid) {
+    const int4 m = f.meta[r];
+    int2 *ln = reinterpret_cast<int2 *>(base + off);
+    float *w = base + off + 2 * m.w;
+    for (int i = tid; i < m.w; i += kThreads) ln[i] = f.ln[m.x + i];
+    for (int i = tid; i < m.w * m.z; i += kThreads) w[i] = f.w[m.y + i];
+    off = (off + 2 * m.w + m.w * m.z + 3) & ~3;
+    LdsTab t{ln, w, m.z};
+    return t;
+}
+__device__ __forceinline__ float tap_dot(const LdsTab &t, int i, const float *src, int stride) {
+    const int2 ln = t.ln[i];
+    const float *w = t.w + i * t.maxt;
+    float acc = 0.f;
+    for (int k = 0; k < ln.y; ++k) acc = fmaf(w[k], src[(ln.x + k) * stride], acc);
+    return acc;
+}
+
+__global__ __launch_bounds__(kThreads) void k_fovea_flexible2(FlexParams g, FovParams p) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int sl = blockIdx.x, n = blockIdx.y, tid = threadIdx.x;
+    const int oh = g.oh, ow = g.ow, fh = g.fh, fw = g.fw;
+    if (p.mask && !p.mask[n]) {
+        if (sl == 0 && tid < 2) {
+            p.loc_out[2 * n + tid] = p.loc_in[2 * n + tid];
+            p.res_out[2 * n + tid] = p.res_in[2 * n + tid];
+        }
+        return;
+    }
+    const int fbytes = oh * ow, fwords = fbytes >> 2;
+    // LDS: lut[256] | raw[oh*ow] | AE[max(oh*fw, fh*ow)] | B[fh*fw] | C[fh*ow] | tables
+    float *lut = reinterpret_cast<float *>(smem);
+    unsigned char *raw = smem + 1024;
+    float *AE = reinterpret_cast<float *>(raw + ((fbytes + 15) & ~15));
+    const int ae_floats = (max(oh * fw, fh * ow) + 3) & ~3;
+    float *B = AE + ae_floats;
+    float *C = B + ((fh * fw + 3) & ~3);
+    float *tabs = C + ((fh * ow + 3) & ~3);
+
+    // ---- round trips start now
+    const uint32_t *fsrc = reinterpret_cast<const uint32_t *>(p.ring + ((size_t)n * p.fs + sl) * (size_t)fbytes);
+    constexpr int kFW = 7;
+    uint32_t fw_[kFW];
+#pragma unroll
+    for (int k = 0; k < kFW; ++k) fw_[k] = fsrc[min(tid + k * kThreads, fwords - 1)];
+    const LocIn lin = load_loc_inputs(p, n);
+    const int2 res_old = *reinterpret_cast<const int2 *>(p.res_in + 2 * n);
+    const int type = (p.action && p.action_type) ? p.action_type[n] : AGX_FOV_LOC;
+    const int head = p.head[n];
+    lut[tid] = unit((uint32_t)tid);
+    // ---- state update (fov_env.py:300-324)
+    int rh = res_old.x, rw = res_old.y, r, c;
+    if (p.action && type == AGX_FOV_RES) {
+        rh = clip_rint(action_value(p.action_dt, lin.w[0], lin.w[1]), 1.0, (double)oh);
+        rw = clip_rint(action_value(p.action_dt, lin.w[2], lin.w[3]), 1.0, (double)ow);
+        r = clip_rint((double)lin.r, 0.0, (double)(oh - rh));
+        c = clip_rint((double)lin.c, 0.0, (double)(ow - rw));
+    } else {
+        compute_loc(p, lin, oh - rh, ow - rw, r, c);
+    }
+    int j = sl - head;
+    if (j < 0) j += p.fs;
+    if (sl == 0 && tid == 0) {
+        p.loc_out[2 * n] = r;
+        p.loc_out[2 * n + 1] = c;
+        p.res_out[2 * n] = rh;
+        p.res_out[2 * n + 1] = rw;
+        if (p.user_loc) {
+            p.user_loc[2 * n] = r;
+            p.user_loc[2 * n + 1] = c;
+        }
+        if (p.user_res) {
+            p.user_res[2 * n] = rh;
+            p.user_res[2 * n + 1] = rw;
+        }
+    }
+    const bool squeeze = rh > fh;                                 // rows only, fov_env.py:286
+    const bool resize = p.out_mode == AGX_OUT_RESIZE;
+    // ---- stage the tables this window needs (L2 hits; their latency hides under the frame load)
+    int toff = 0;
+    LdsTab wd{}, hd{}, wb{}, hb{}, wf{}, hf{};
+    if (squeeze) {
+        wd = stage_tab(g.wd, rw, tabs, toff, tid);
+        hd = stage_tab(g.hd, rh, tabs, toff, tid);
+        wb = stage_tab(g.wb, rw, tabs, toff, tid);
+        hb = stage_tab(g.hb, rh, tabs, toff, tid);
+    }
+    if (resize) {
+        wf = stage_tab(g.wf, rw, tabs, toff, tid);
+        hf = stage_tab(g.hf, rh, tabs, toff, tid);
+    }
+#pragma unroll
+    for (int k = 0; k < kFW; ++k)
+        if (tid + k * kThreads < fwords) reinterpret_cast<uint32_t *>(raw)[tid + k * kThreads] = fw_[k];
+    for (int i = tid + kFW * kThreads; i < fwords; i += kThreads) reinterpret_cast<uint32_t *>(raw)[i] = fsrc[i];
+    __syncthreads();
+
+    const unsigned char *win = raw + r * ow + c;
+    const float kInv255 = 1.0f / 255.0f;          // resampling inputs only (<= 1 ulp from k/255); pasted pixels use lut
+    const int ow4 = ow >> 2;
+    float4 *out4 = reinterpret_cast<float4 *>(p.obs) + ((size_t)n * p.fs + j) * (size_t)(oh * ow4);
+
+    if (squeeze) {
+        // P1: A[y][xf] = Wdwn(crop)      y < rh, xf < fw
+        for (int i = tid; i < rh * fw; i += kThreads) {
+            const int y = i / fw, xf = i - y * fw;
+            const int2 ln = wd.ln[xf];
+            const float *w = wd.w + xf * wd.maxt;
+            const unsigned char *src = win + y * ow + ln.x;
+            float acc = 0.f;
+            for (int k = 0; k < ln.y; ++k) acc = fmaf(w[k], (float)src[k], acc);
+            AE[i] = acc * kInv255;
+        }
+        __syncthreads();
+        // P2: B[yf][xf] = Hdwn(A)
+        for (int i = tid; i < fh * fw; i += kThreads) {
+            const int yf = i / fw, xf = i - yf * fw;
+            B[i] = tap_dot(hd, yf, AE + xf, fw);
+        }
+        __syncthreads();
+        // P3: C[yf][x] = Wbck(B)         x < rw
+        for (int i = tid; i < fh * rw; i += kThreads) {
+            const int yf = i / rw, x = i - yf * rw;
+            C[yf * ow + x] = tap_dot(wb, x, B + yf * fw, 1);
+        }
+        __syncthreads();
+    }
+
+    if (resize) {
+        // E[y][xo] = Wfin(src rows): src = C (fh rows) after a squeeze, else the crop itself (rh rows)
+        const int erows = squeeze ? fh : rh;
+        for (int i = tid; i < erows * ow; i += kThreads) {
+            const int y = i / ow, xo = i - y * ow;
+            const int2 ln = wf.ln[xo];
+            const float *w = wf.w + xo * wf.maxt;
+            float acc = 0.f;
+            if (squeeze) {
+                for (int k = 0; k < ln.y; ++k) acc = fmaf(w[k], C[y * ow + ln.x + k], acc);
+            } else {
+                const unsigned char *src = win + y * ow + ln.x;
+                for (int k = 0; k < ln.y; ++k) acc = fmaf(w[k], (float)src[k], acc);
+                acc *= kInv255;
+            }
+            AE[i] = acc;
+        }
+        __syncthreads();
+        const float4 *E4 = reinterpret_cast<const float4 *>(AE);
+        for (int q = tid; q < oh * ow4; q += kThreads) {
+            const int row = q / ow4, x4 = q - row * ow4;
+            const int2 lnf = hf.ln[row];
+            const float *wfv = hf.w + row * hf.maxt;
+            float4 o = make_float4(0.f, 0.f, 0.f, 0.f);
+            for (int a = 0; a < lnf.y; ++a) {
+                const int ya = lnf.x + a;                      // row of the (virtual) rh-row image
+                if (squeeze) {
+                    const int2 lnb = hb.ln[ya];
+                    const float *wbv = hb.w + ya * hb.maxt;
+                    for (int b = 0; b < lnb.y; ++b) {
+                        const float ww = wfv[a] * wbv[b];
+                        const float4 v = E4[(lnb.x + b) * ow4 + x4];
+                        o.x = fmaf(ww, v.x, o.x);
+                        o.y = fmaf(ww, v.y, o.y);
+                        o.z = fmaf(ww, v.z, o.z);
+                        o.w = fmaf(ww, v.w, o.w);
+                    }
+                } else {
+                    const float4 v = E4[ya * ow4 + x4];
+                    o.x = fmaf(wfv[a], v.x, o.x);
+                    o.y = fmaf(wfv[a], v.y, o.y);
+                    o.z = fmaf(wfv[a], v.z, o.z);
+                    o.w = fmaf(wfv[a], v.w, o.w);
+                }
+            }
+            store_obs(&out4[q], o);
+        }
+        return;
+    }
+    // mask-out paste at (r, c) / raw crop at the origin of the obs-pitched buffer
+    const int pr = (p.out_mode == AGX_OUT_MASK) ? r : 0;
+    const int pc = (p.out_mode == AGX_OUT_MASK) ? c : 0;
+    for (int q = tid; q < oh * ow4; q += kThreads) {
+        const int row = q / ow4, x = (q - row * ow4) * 4;
+        const int y = row - pr;
+        float v[4] = {0.f, 0.f, 0.f, 0.f};
+        if (y >= 0 && y < rh) {
+            int2 lnb = make_int2(0, 0);
+            const float *wbv = nullptr;
+            if (squeeze) {
+                lnb = hb.ln[y];
+                wbv = hb.w + y * hb.maxt;
+            }
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const int xx = x + k - pc;
+                if (xx >= 0 && xx < rw) {
+                    if (squeeze) {
+                        float acc = 0.f;
+                        for (int b = 0; b < lnb.y; ++b) acc = fmaf(wbv[b], C[(lnb.x + b) * ow + xx], acc);
+                        v[k] = acc;
+                    } else {
+                        v[k] = lut[win[y * ow + xx]];
+                    }
+                }
+            }
+        }
+        store_obs(&out4[q], make_float4(v[0], v[1], v[2], v[3]));
+    }
+}
+
 // fov_loc / fov_res (re)initialisation for masked envs (fov_env.py:149-150,250-251)
 struct FovResetParams {
     const uint8_t *mask;
