@@ -506,7 +506,17 @@ int agx_ingest(agx_ctx *ctx, const uint8_t *d_frames, const uint8_t *d_cmd, void
     if (const char *e = getenv("AGX_DBG_PTR")) p.stamps = reinterpret_cast<unsigned long long *>(strtoull(e, nullptr, 0));
 #endif
     static const int pipe_parts = [] { const char *e = getenv("AGX_INGEST_PIPE"); return e ? atoi(e) : 0; }();
-    if (pipe_parts > 0 && ctx->ingest_t == 256) {
+    // wave-private form: needs the affine row form, band_rows = 4 * RPW with RPW * ow/4 <= 64 lanes and
+    // 2 frames * RPW rows * 40 pieces <= 240 (RPW <= 3)
+    // (measured equal to the barrier form at N=1024 - 46.5 vs 45.6 us - so it is opt-in: AGX_INGEST_WAVE=1)
+    static const bool want_wave = getenv("AGX_INGEST_WAVE") != nullptr;
+    const int rpw = ctx->band_rows / 4;
+    const bool wave_ok = want_wave && pipe_parts == 0 && ctx->ingest_t == 256 && ctx->y_affine && ctx->band_rows % 4 == 0 &&
+                         rpw >= 1 && rpw <= 3 && rpw * (c.obs_w / 4) <= 64;
+    if (wave_ok) {
+        const size_t slice = ((sizeof(int2) * c.obs_w + (size_t)2 * rpw * kRawW * 2) + 15) & ~(size_t)15;
+        hipLaunchKernelGGL(k_ingest_wave, dim3(bands, c.num_envs), dim3(256), 4 * slice, S(stream), p);
+    } else if (pipe_parts > 0 && ctx->ingest_t == 256) {
         const int parts = std::min(pipe_parts, bands);
         const size_t lds2 = sizeof(int4) * c.obs_h + sizeof(int2) * c.obs_w + (size_t)2 * (2 * ctx->band_rows * 2 * kRawW);
         hipLaunchKernelGGL(k_ingest_pipe<256>, dim3(parts, c.num_envs), dim3(256), lds2, S(stream), p);

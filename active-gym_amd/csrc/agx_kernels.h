@@ -352,6 +352,159 @@ __global__ __launch_bounds__(T) void k_ingest(IngestParams p) {
 }
 
 // ---------------------------------------------------------------------------------------------
+// K1, wave-private form (opt-in, AGX_INGEST_WAVE=1): grid = (bands, N), block = 256, but
+// the 4 waves of a workgroup never meet.  Wave w owns RPW = band_rows/4 output rows end to end:
+// it loads their source rows for both frames (60 of its 64 lanes x 4 pieces = 240 twelve-byte
+// pieces = 3 rows x 2 frames x 40), turns them into gray bytes in ITS slice of LDS, and produces its
+// own 3 x ow/4 (= 63) output dwords.  No __syncthreads: LDS traffic of one wave is ordered by the
+// hardware, so only a wavefront-scope fence separates the phases.  (s_memtime stamps of the
+// barrier version: 16 % of a wave's life waiting at the barrier, on top of inter-wave skew.)
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(kThreads) void k_ingest_wave(IngestParams p) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    constexpr int T = kThreads;                                           // (AGX_STAMP uses T)
+    (void)T;
+    const int n = blockIdx.y, band = blockIdx.x, tid = threadIdx.x;
+    const int wave = tid >> 6, lane = tid & 63;
+    AGX_STAMP(0);
+    const int BR = p.band_rows, RPW = BR >> 2;                            // rows per wave (3 for 84x84)
+    const int dy0 = band * BR + wave * RPW;                               // first output row of this wave
+    const int rows = max(0, min(RPW, p.oh - dy0));
+    const int ow4 = p.ow >> 2;
+    // per-wave LDS slice: xtab[ow] int2 | gray[2][RPW][160][2]
+    const int slice = (int)sizeof(int2) * p.ow + 2 * RPW * kRawW * 2;
+    unsigned char *mine = smem + wave * ((slice + 15) & ~15);
+    int2 *xtab_s = reinterpret_cast<int2 *>(mine);
+    unsigned char *gray = mine + sizeof(int2) * p.ow;
+
+    constexpr int G4 = kRawW / 4, LPI = 60, kIter = 4;                    // 60 lanes x 4 = 240 pieces
+    const uint8_t *fbase = p.frames + (size_t)n * 2 * kRawFrameBytes;
+    int nvalid = 2;                                                       // speculative until cmd arrives
+    auto piece = [&](int it, uint32_t &o0, uint32_t &o1, int &d) {
+        const int ntask = max(nvalid, 1) * max(rows, 1) * G4;
+        const int t_raw = it * LPI + lane;
+        const int task = min(t_raw, ntask - 1);
+        const int rj = task / G4, g4 = task - rj * G4;                    // rj = f * rows + dl
+        const int f = rj >= rows ? 1 : 0;
+        const int dl = rj - f * rows;
+        const int dy = min(dy0 + dl, p.oh - 1);
+        const int y0 = (int)(mul_u24((uint32_t)dy, (uint32_t)p.y_mul) + (uint32_t)p.y_add) >> p.y_shift;
+        const int y1 = min(y0 + 1, kRawH - 1);
+        const uint32_t fo = f * kRawFrameBytes + g4 * 12;
+        o0 = mad_u24((uint32_t)y0, kRawRowBytes, fo);
+        o1 = mad_u24((uint32_t)y1, kRawRowBytes, fo);
+        d = (lane < LPI && t_raw < nvalid * rows * G4) ? ((f * RPW + dl) * kRawW + g4 * 4) * 2 : -1;
+    };
+    U3 w0[kIter], w1[kIter];
+    int dst[kIter];
+#pragma unroll
+    for (int it = 0; it < kIter; ++it) {
+        uint32_t o0, o1;
+        piece(it, o0, o1, dst[it]);
+        w0[it] = *reinterpret_cast<const U3 *>(fbase + o0);
+        w1[it] = *reinterpret_cast<const U3 *>(fbase + o1);
+    }
+    // phase-2 taps: requested after the frame pieces, parked in this wave's LDS slice
+    const int dl2 = lane / ow4, xq = lane - dl2 * ow4;
+    const bool p2 = lane < rows * ow4;
+    const int4 yt2 = p.ytab[min(dy0 + dl2, p.oh - 1)];
+    int2 xt_own[2];
+    xt_own[0] = p.xtab[min(lane, p.ow - 1)];
+    xt_own[1] = p.xtab[min(lane + 64, p.ow - 1)];
+    const uint32_t cmd = uniform_load_u8(p.cmd + n);
+    const int head = uniform_load_i32(p.head_in + n);
+    const bool skip = (cmd & AGX_CMD_SKIP) != 0;
+    const bool clear = (cmd & AGX_CMD_CLEAR) != 0;
+    if (band == 0 && tid == 0) p.head_out[n] = skip ? head : (clear ? 0 : (head + 1 == p.fs ? 0 : head + 1));
+    if (skip || rows == 0) return;
+    nvalid = min((int)(cmd & AGX_CMD_NVALID_MASK), 2);
+    const int slot = clear ? p.fs - 1 : head;
+    AGX_STAMP(1);
+    if (nvalid > 0) {
+        uint32_t tie_its = 0;
+#pragma unroll
+        for (int it = 0; it < kIter; ++it) {
+            bool tie = false;
+            const uint32_t top = lum4(w0[it].x, w0[it].y, w0[it].z, tie);
+            const uint32_t bot = lum4(w1[it].x, w1[it].y, w1[it].z, tie);
+            if (it * LPI + lane >= nvalid * rows * G4) dst[it] = -1;      // frame-1 pieces are void when nvalid == 1
+            if (dst[it] >= 0) {
+                uint2 v;                                                  // t0 b0 t1 b1 | t2 b2 t3 b3
+                v.x = __builtin_amdgcn_perm(bot, top, 0x05010400u);
+                v.y = __builtin_amdgcn_perm(bot, top, 0x07030602u);
+                *reinterpret_cast<uint2 *>(gray + dst[it]) = v;
+                tie_its |= tie ? (1u << it) : 0u;
+            }
+        }
+        if (__builtin_expect(tie_its != 0, 0)) {                          // exact .5 luminance ties, ~1e-4 of pixels
+#pragma nounroll
+            for (int it = 0; it < kIter; ++it) {
+                if (!((tie_its >> it) & 1u)) continue;
+                uint32_t o0, o1;
+                int d;
+                piece(it, o0, o1, d);
+                const U3 a = *reinterpret_cast<const U3 *>(fbase + o0);
+                const U3 b = *reinterpret_cast<const U3 *>(fbase + o1);
+#pragma nounroll
+                for (int j = 0; j < 8; ++j) {
+                    const bool which = j & 1;
+                    const int k = j >> 1;
+                    const uint32_t x = which ? b.x : a.x, y = which ? b.y : a.y, z = which ? b.z : a.z;
+                    const uint64_t lo = (uint64_t)x | ((uint64_t)y << 32);
+                    const uint64_t hi = (uint64_t)y | ((uint64_t)z << 32);
+                    const uint32_t px = (uint32_t)(k < 2 ? (lo >> (24 * k)) : (hi >> (24 * k - 32)));
+                    gray[d + j] = (unsigned char)ale_lum_exact(px & 0xFF, (px >> 8) & 0xFF, (px >> 16) & 0xFF);
+                }
+            }
+        }
+        if (lane < p.ow) xtab_s[lane] = xt_own[0];
+        if (lane + 64 < p.ow) xtab_s[lane + 64] = xt_own[1];
+        for (int i = lane + 128; i < p.ow; i += 64) xtab_s[i] = p.xtab[i];
+    }
+    AGX_STAMP(2);
+    // this wave's LDS writes are consumed by other lanes of the SAME wave only
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    AGX_STAMP(3);
+    if (p2) {
+        const int dy = dy0 + dl2;
+        uint32_t packed = 0;
+        if (nvalid > 0) {
+            const uint32_t b0 = (uint32_t)yt2.z, b1 = (uint32_t)yt2.w;
+            const int4 xt01 = *reinterpret_cast<const int4 *>(xtab_s + xq * 4);
+            const int4 xt23 = *reinterpret_cast<const int4 *>(xtab_s + xq * 4 + 2);
+            const int xi[4] = {xt01.x, xt01.z, xt23.x, xt23.z};
+            const int xa[4] = {xt01.y, xt01.w, xt23.y, xt23.w};
+            const unsigned char *row0 = gray + mul_u24((uint32_t)dl2, kRawW * 2);
+            const uint32_t fstride = (uint32_t)RPW * kRawW * 2;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const uint32_t x0 = xi[k] & 0xFFFF, x1 = (uint32_t)xi[k] >> 16;
+                const uint32_t a0 = xa[k] & 0xFFFF, a1 = (uint32_t)xa[k] >> 16;
+                uint32_t best = 0;
+                for (int f = 0; f < nvalid; ++f) {
+                    const uint16_t *row = reinterpret_cast<const uint16_t *>(row0 + f * fstride);
+                    const uint32_t p0 = row[x0], p1 = row[x1];           // lo byte: row y0, hi byte: row y1
+                    const uint32_t h0 = mad_u24(p1 & 0xFF, a1, mul_u24(p0 & 0xFF, a0));
+                    const uint32_t h1 = mad_u24(p1 >> 8, a1, mul_u24(p0 >> 8, a0));
+                    const uint32_t v = (((mul_u24(b0, h0 >> 4) >> 16) + (mul_u24(b1, h1 >> 4) >> 16) + 2) >> 2) & 0xFF;
+                    best = max(best, v);
+                }
+                packed |= best << (8 * k);
+            }
+        }
+        const uint32_t fsz = (uint32_t)p.oh * p.ow;
+        uint8_t *env = p.ring + (size_t)n * p.fs * fsz;
+        const uint32_t off = mad_u24((uint32_t)dy, (uint32_t)p.ow, (uint32_t)xq * 4);
+        *reinterpret_cast<uint32_t *>(env + (slot * fsz + off)) = packed;
+        if (clear)
+            for (int s = 0; s < p.fs - 1; ++s) *reinterpret_cast<uint32_t *>(env + (s * fsz + off)) = 0u;
+    }
+    AGX_STAMP(4);
+}
+
+// ---------------------------------------------------------------------------------------------
 // K1, pipelined form: grid = (P, N), block = 256.  Workgroup (part, n) walks bands part, part+P, ...
 // of env n.  The NEXT band's source pieces are requested (registers B) before the current band's
 // luminance (registers A) is computed, so every wave has loads in flight for its whole life instead
