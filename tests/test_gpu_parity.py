@@ -409,3 +409,85 @@ def test_full_size_properties(dev):
     # (4) torch's own bilinear on the same window (float32 reference of the float kernel)
     ref = torch.nn.functional.interpolate(win, size=(84, 84), mode="bilinear", align_corners=False)
     assert (obs_z - ref).abs().max().item() <= FLOAT_TOL
+
+
+# ---------------------------------------------------------------- ABI error behaviour
+def test_abi_error_paths(dev):
+    import ctypes as C
+    from active_gym import _native as nat
+    lib = nat.lib()
+
+    def make(**over):
+        cfg = nat.AgxConfig()
+        cfg.struct_size = C.sizeof(nat.AgxConfig)
+        cfg.device, cfg.num_envs, cfg.kind = 0, 4, nat.KIND_FIXED
+        cfg.raw_h, cfg.raw_w, cfg.obs_h, cfg.obs_w, cfg.frame_stack = 210, 160, 84, 84, 4
+        cfg.fov_h, cfg.fov_w, cfg.out_mode, cfg.action_mode, cfg.antialias = 30, 30, nat.OUT_RESIZE, nat.MODE_ABSOLUTE, 1
+        for k, v in over.items():
+            setattr(cfg, k, v)
+        ctx = C.c_void_p()
+        rc = lib.agx_create(C.byref(cfg), C.byref(ctx))
+        return rc, ctx
+
+    for over, frag in [(dict(num_envs=0), "num_envs"), (dict(num_envs=70000), "num_envs"), (dict(raw_h=200), "raw screen"),
+                       (dict(obs_w=86), "obs_size"), (dict(frame_stack=0), "frame_stack"), (dict(frame_stack=17), "frame_stack"),
+                       (dict(fov_h=84), "fov_size"), (dict(fov_w=0), "fov_size"), (dict(kind=9), "kind"),
+                       (dict(out_mode=5), "out_mode"), (dict(action_mode=3), "action_mode"), (dict(device=99), "device"),
+                       (dict(action_mode=nat.MODE_RELATIVE, sas_lo=2.0, sas_hi=1.0), "sensory_action_space"),
+                       (dict(kind=nat.KIND_PERIPHERAL, per_h=0, per_w=20), "peripheral_res")]:
+        rc, ctx = make(**over)
+        assert rc == nat.E_INVALID and not ctx.value, over
+        assert frag in nat.last_error(None), (over, nat.last_error(None))
+    cfg_bad = dict(init_loc=(C.c_double * 2)(60.0, 0.0))
+    rc, ctx = make(**cfg_bad)
+    assert rc == nat.E_INVALID and "fov_init_loc" in nat.last_error(None)
+
+    rc, ctx = make()
+    assert rc == nat.OK and ctx.value
+    obs = torch.empty((4, 4, 84, 84), device=dev)
+    P = C.c_void_p
+    # wrong wrapper kind for this context
+    assert lib.agx_fovea_peripheral(ctx, None, 0, None, P(obs.data_ptr()), None, None) == nat.E_STATE
+    assert "kind" in nat.last_error(ctx)
+    assert lib.agx_fovea_flexible(ctx, None, 0, None, None, P(obs.data_ptr()), None, None, None) == nat.E_STATE
+    # null buffers / bad dtype
+    assert lib.agx_fovea_fixed(ctx, None, 0, None, None, None, None) == nat.E_INVALID
+    assert lib.agx_ingest(ctx, None, None, None) == nat.E_INVALID
+    assert lib.agx_fovea_fixed(ctx, P(obs.data_ptr()), 7, None, P(obs.data_ptr()), None, None) == nat.E_INVALID
+    assert "dtype" in nat.last_error(ctx)
+    assert lib.agx_algorithmic_bytes(ctx, nat.K_FOVEA) == 4 * 4 * (900 + 4 * 7056)
+    assert lib.agx_algorithmic_bytes(ctx, nat.K_INGEST) == 4 * (2 * 168 * 480 + 7056)
+    assert lib.agx_algorithmic_bytes(ctx, 99) == nat.E_INVALID
+    assert lib.agx_destroy(ctx) == nat.OK
+    # base context has no fovea
+    rc, ctx = make(kind=nat.KIND_BASE)
+    assert rc == nat.OK
+    assert lib.agx_fovea_reset(ctx, None, None) == nat.E_STATE and lib.agx_fovea_fixed(ctx, None, 0, None, P(obs.data_ptr()), None, None) == nat.E_STATE
+    assert lib.agx_destroy(ctx) == nat.OK and lib.agx_destroy(None) == nat.OK
+    torch.cuda.synchronize()
+
+
+def test_large_and_odd_batches(dev):
+    """N not a multiple of anything, and a batch big enough to exceed one round of workgroups."""
+    for N in (1, 3, 257, 2000):
+        rng = np.random.default_rng(N)
+        p = _pipe(num_envs=N, kind="fixed", obs_size=(84, 84), fov_size=(30, 30), frame_stack=4, resize_to_full=True)
+        st = torch.randint(0, 256, (N, 4, 84, 84), dtype=torch.uint8, device=dev)
+        p.set_stack_u8(st)
+        a = torch.rand((N, 2), device=dev) * 54
+        obs, loc = p.fovea(a)
+        want_loc = torch.round(a.clamp(0, 54)).to(torch.int32)            # round-half-even like rint
+        assert torch.equal(loc, want_loc)
+        ar = torch.arange(30, device=dev)
+        full = st.float() / 255.0
+        idx = torch.arange(N, device=dev)
+        win = full[idx[:, None, None, None], torch.arange(4, device=dev)[None, :, None, None],
+                   (loc[:, 0:1] + ar).long()[:, None, :, None], (loc[:, 1:2] + ar).long()[:, None, None, :]]
+        ref = torch.nn.functional.interpolate(win, size=(84, 84), mode="bilinear", align_corners=False)
+        assert (obs - ref).abs().max().item() <= FLOAT_TOL
+        if N <= 3:
+            frames = rng.integers(0, 256, (N, 2, 210, 160, 3), dtype=np.uint8)
+            p.ingest(_t(frames, dev), torch.full((N,), 2, dtype=torch.uint8, device=dev))
+            newest = p.stack_u8()[:, -1].cpu().numpy()
+            for i in range(N):
+                assert np.array_equal(newest[i], np.maximum(O.get_state_u8(frames[i, 0], (84, 84)), O.get_state_u8(frames[i, 1], (84, 84))))
