@@ -230,12 +230,8 @@ __global__ __launch_bounds__(T) void k_ingest(IngestParams p) {
         w0[it] = *reinterpret_cast<const U3 *>(fbase + o0);
         w1[it] = *reinterpret_cast<const U3 *>(fbase + o1);
     }
-#if defined(AGX_ABL) && AGX_ABL == 13
-    const uint32_t cmd = 2; const int head = n & 3;
-#else
     const uint32_t cmd = uniform_load_u8(p.cmd + n);
     const int head = uniform_load_i32(p.head_in + n);
-#endif
     const bool skip = (cmd & AGX_CMD_SKIP) != 0;
     const bool clear = (cmd & AGX_CMD_CLEAR) != 0;
     if (band == 0 && tid == 0) p.head_out[n] = skip ? head : (clear ? 0 : (head + 1 == p.fs ? 0 : head + 1));
@@ -256,12 +252,8 @@ __global__ __launch_bounds__(T) void k_ingest(IngestParams p) {
 #pragma unroll
         for (int it = 0; it < kIter; ++it) {
             bool tie = false;
-#if defined(AGX_ABL) && AGX_ABL == 11
-            const uint32_t top = w0[it].x ^ w0[it].y ^ w0[it].z, bot = w1[it].x ^ w1[it].y ^ w1[it].z;
-#else
             const uint32_t top = lum4(w0[it].x, w0[it].y, w0[it].z, tie);
             const uint32_t bot = lum4(w1[it].x, w1[it].y, w1[it].z, tie);
-#endif
             if (dst[it] >= 0) {
                 uint2 v;                                                  // t0 b0 t1 b1 | t2 b2 t3 b3
                 v.x = __builtin_amdgcn_perm(bot, top, 0x05010400u);
@@ -270,7 +262,6 @@ __global__ __launch_bounds__(T) void k_ingest(IngestParams p) {
                 tie_its |= tie ? (1u << it) : 0u;
             }
         }
-#ifndef AGX_K1_NOTIE
         if (__builtin_expect(tie_its != 0, 0)) {
             // about 1e-4 of random pixels sit on an exact .5 tie: redo those pieces byte by byte with
             // the exact rule.  The source bytes are re-read (L2 hits) so that the fast path does not
@@ -295,7 +286,6 @@ __global__ __launch_bounds__(T) void k_ingest(IngestParams p) {
                 }
             }
         }
-#endif
         if (tid < rows) ytab_s[tid] = yt_own;
         if (tid < p.ow) xtab_s[tid] = xt_own;
         for (int i = tid + T; i < p.ow; i += T) xtab_s[i] = p.xtab[i];
@@ -322,9 +312,6 @@ __global__ __launch_bounds__(T) void k_ingest(IngestParams p) {
         const int xa[4] = {xt01.y, xt01.w, xt23.y, xt23.w};
         const unsigned char *row0 = gray + mul_u24((uint32_t)dyl, kRawW * 2);      // frame 0, this output row
         const uint32_t fstride = (uint32_t)BR * kRawW * 2;                         // wave-uniform
-#if defined(AGX_ABL) && AGX_ABL == 12
-        packed = *reinterpret_cast<const uint32_t *>(row0 + xq * 4) + b0 + xi[0] + xa[3];
-#else
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
             const uint32_t x0 = xi[k] & 0xFFFF, x1 = (uint32_t)xi[k] >> 16;
@@ -340,7 +327,6 @@ __global__ __launch_bounds__(T) void k_ingest(IngestParams p) {
             }
             packed |= best << (8 * k);
         }
-#endif
         const uint32_t fsz = (uint32_t)p.oh * p.ow;
         uint8_t *env = p.ring + (size_t)n * p.fs * fsz;                            // wave-uniform
         const uint32_t off = mad_u24((uint32_t)dy, (uint32_t)p.ow, (uint32_t)xq * 4);

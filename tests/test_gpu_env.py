@@ -237,3 +237,25 @@ def test_recording_buffer_keys(tmp_path):
     saved = torch.load(path, weights_only=False)
     assert isinstance(saved["rgb"], str) and len(saved["reward"]) == n
     env.close()
+
+
+def test_bench_contract_json():
+    """bench.py prints ONE JSON line with the driver's contract fields (small, quick configuration)."""
+    import json, os, subprocess, sys
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = subprocess.run([sys.executable, os.path.join(repo, "bench.py"), "--steps", "8", "--warmup", "2", "--envs", "64",
+                          "--cpu-seconds", "0.5"], capture_output=True, text=True, timeout=600, cwd=repo)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+              "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):
+        assert k in d, k
+    assert d["n_gpus"] == 1 and d["steps"] == 8 and d["warmup"] == 2 and d["scaling"] == "weak" and d["vs_baseline"] is None
+    assert d["higher_is_better"] is True and d["data"] == "synthetic" and "workload" in d["config"] and "model" not in d["config"]
+    r = d["roofline"]
+    assert r["bound"] == "hbm" and r["unit"] == "GB/s" and r["peak"] == 8000.0 and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-9
+    c = d["cpu_baseline"]
+    assert c["kind"] == "port" and c["cores"] == 1 and c["value"] > 0 and "sample" in c
+    assert abs(d["value"] - 64 * 8 / (d["ms_per_step"] * 8e-3)) / d["value"] < 1e-6
