@@ -244,7 +244,7 @@ def test_bench_contract_json():
     import json, os, subprocess, sys
     repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     out = subprocess.run([sys.executable, os.path.join(repo, "bench.py"), "--steps", "8", "--warmup", "2", "--envs", "64",
-                          "--cpu-seconds", "0.5"], capture_output=True, text=True, timeout=600, cwd=repo)
+                          "--cpu-seconds", "3"], capture_output=True, text=True, timeout=600, cwd=repo)
     assert out.returncode == 0, out.stderr[-2000:]
     lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
     assert len(lines) == 1
@@ -257,5 +257,5 @@ def test_bench_contract_json():
     r = d["roofline"]
     assert r["bound"] == "hbm" and r["unit"] == "GB/s" and r["peak"] == 8000.0 and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-9
     c = d["cpu_baseline"]
-    assert c["kind"] == "port" and c["cores"] == 1 and c["value"] > 0 and "sample" in c
+    assert c["kind"] == "port" and c["cores"] >= 1 and c["value"] > 0 and "sample" in c
     assert abs(d["value"] - 64 * 8 / (d["ms_per_step"] * 8e-3)) / d["value"] < 1e-6
