@@ -146,18 +146,36 @@ struct IngestParams {
     // y0(dy) == (dy * y_mul + y_add) >> y_shift and y1 == min(y0 + 1, raw_h - 1) for every dy (checked
     // exhaustively against ytab at agx_create); lets the frame loads start without a table round trip.
     int32_t y_affine, y_mul, y_add, y_shift;
-    unsigned long long *stamps;   // diagnostic builds only (AGX_STAMPS): [workgroup][wave][6] s_memtime values
+    unsigned long long *stamps;   // diagnostic builds only (AGX_STAMPS): [workgroup][wave][8] records
 };
 
 #ifdef AGX_STAMPS
+// slot 5 of every wave's record holds where it ran: XCC_ID | HW_ID << 8 (se/cu/simd/wave slot)
 #define AGX_STAMP(i)                                                                              \
     do {                                                                                          \
         __builtin_amdgcn_sched_barrier(0);                                                        \
         unsigned long long t_;                                                                    \
         asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory");               \
         __builtin_amdgcn_sched_barrier(0);                                                        \
-        if (p.stamps && (threadIdx.x & 63) == 0)                                                  \
-            p.stamps[(((size_t)blockIdx.y * gridDim.x + blockIdx.x) * (T / 64) + (threadIdx.x >> 6)) * 6 + (i)] = t_; \
+        if (p.stamps && (threadIdx.x & 63) == 0) {                                                \
+            unsigned long long *rec_ = p.stamps +                                                 \
+                (((size_t)blockIdx.y * gridDim.x + blockIdx.x) * (T / 64) + (threadIdx.x >> 6)) * 8; \
+            rec_[(i)] = t_;                                                                       \
+            if ((i) == 0) {                                                                       \
+                unsigned xcc_, hw_;                                                               \
+                asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc_));               \
+                asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw_));                 \
+                unsigned long long rt_;                                                           \
+                asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(rt_)::"memory");  \
+                rec_[5] = ((unsigned long long)hw_ << 8) | (xcc_ & 0xFF);                         \
+                rec_[6] = rt_;                                                                    \
+            }                                                                                     \
+            if ((i) == 4) {                                                                       \
+                unsigned long long rt_;                                                           \
+                asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(rt_)::"memory");  \
+                rec_[7] = rt_;                                                                    \
+            }                                                                                     \
+        }                                                                                         \
     } while (0)
 #else
 #define AGX_STAMP(i) do {} while (0)

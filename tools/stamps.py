@@ -1,11 +1,11 @@
 #!/usr/bin/env python3
-"""Diagnostic: per-wave s_memtime stamps of k_ingest (needs a -DAGX_STAMPS build passed via AGX_LIB)."""
+"""Diagnostic: per-wave s_memtime / s_memrealtime stamps + placement of k_ingest (needs a -DAGX_STAMPS build, AGX_LIB)."""
 import os, sys
 sys.path[:0] = [os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "active-gym_amd")]
 import numpy as np, torch
 dev = torch.device("cuda:0")
 N = 1024
-st = torch.zeros((N * 7 * 4, 6), dtype=torch.int64, device=dev)
+st = torch.zeros((N * 7 * 4, 8), dtype=torch.int64, device=dev)
 os.environ["AGX_DBG_PTR"] = str(st.data_ptr())
 from active_gym import ObsPipeline
 p = ObsPipeline(num_envs=N, kind="fixed", fov_size=(30, 30), resize_to_full=True, device=dev)
@@ -17,17 +17,30 @@ obs = torch.empty(p.obs_shape, device=dev)
 for k in range(6):
     p.ingest(frames[k % 4], cmd); p.fovea(act, out=obs)
 torch.cuda.synchronize()
-s = st.cpu().numpy().astype(np.float64)
-d = np.diff(s[:, :5], axis=1)          # 4 segments
-names = ["prologue+issue", "lum+LDS write", "barrier wait", "phase2+store"]
-t0 = s[:, 0].min()
-print("kernel span (cycles @100MHz memtime?):", s[:, 4].max() - t0)
-for i, nme in enumerate(names):
-    print(f"{nme:16s} mean {d[:, i].mean():9.0f}  p50 {np.median(d[:, i]):9.0f}  p90 {np.percentile(d[:, i], 90):9.0f}")
-print("wave life mean", (s[:, 4] - s[:, 0]).mean(), " start spread p50/p99", np.percentile(s[:, 0] - t0, 50), np.percentile(s[:, 0] - t0, 99))
-# timeline occupancy: how many waves alive over time
-life = np.stack([s[:, 0] - t0, s[:, 4] - t0], 1)
-T = life[:, 1].max()
-for frac in (0.1, 0.3, 0.5, 0.7, 0.9):
-    t = frac * T
-    print(f"t={frac:.1f}: waves alive {(np.logical_and(life[:,0] <= t, life[:,1] > t)).sum()}")
+s = st.cpu().numpy()
+cyc = s[:, :5].astype(np.float64)
+d = np.diff(cyc, axis=1)
+for i, nme in enumerate(["issue+cmd wait", "lum+LDS write", "barrier wait", "phase2+store"]):
+    print(f"{nme:16s} mean {d[:, i].mean():9.0f}  p50 {np.median(d[:, i]):9.0f}  p90 {np.percentile(d[:, i], 90):9.0f} cycles")
+life_c = cyc[:, 4] - cyc[:, 0]
+rt0, rt1 = s[:, 6].astype(np.float64), s[:, 7].astype(np.float64)          # 100 MHz constant clock
+life_us = (rt1 - rt0) / 100.0
+print("wave life: %.0f cycles = %.2f us  -> shader clock %.2f GHz" % (life_c.mean(), life_us.mean(), life_c.mean() / life_us.mean() / 1e3))
+t0 = rt0.min(); span = (rt1.max() - t0) / 100.0
+print("kernel span by memrealtime: %.1f us" % span)
+xcc = s[:, 5] & 0xFF; hw = s[:, 5] >> 8
+cu = (hw >> 8) & 0xF; se = (hw >> 13) & 0x7; sh = (hw >> 12) & 1
+cuid = xcc * 1000 + se * 100 + sh * 50 + cu
+ids = np.unique(cuid)
+print("distinct CUs seen:", len(ids), " waves per CU: min %d max %d" % (np.bincount(np.searchsorted(ids, cuid)).min(), np.bincount(np.searchsorted(ids, cuid)).max()))
+ts = np.linspace(0, span, 41)[1:-1]
+occ = []
+for c in ids[:: max(1, len(ids) // 32)]:
+    m = cuid == c
+    a, b = (rt0[m] - t0) / 100.0, (rt1[m] - t0) / 100.0
+    occ.append([(np.logical_and(a <= t, b > t)).sum() for t in ts])
+occ = np.array(occ)
+print("mean resident waves per CU over time (us : waves):")
+print("  " + "  ".join(f"{t:.0f}:{o:.0f}" for t, o in zip(ts[::3], occ.mean(0)[::3])))
+last_start = np.array([((rt0[cuid == c] - t0) / 100.0).max() for c in ids])
+print("last wave start per CU: mean %.1f us  max %.1f us ; kernel span %.1f" % (last_start.mean(), last_start.max(), span))
