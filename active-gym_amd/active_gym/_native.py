@@ -50,6 +50,7 @@ SIGNATURES = {
     "agx_get_fov_state": (C.c_int, [_P, _P, _P, _P]),
     "agx_set_fov_state": (C.c_int, [_P, _P, _P, _P]),
     "agx_fovea_fixed": (C.c_int, [_P, _P, C.c_int, _P, _P, _P, _P]),
+    "agx_step_fixed": (C.c_int, [_P, _P, _P, _P, C.c_int, _P, _P, _P, _P]),
     "agx_fovea_peripheral": (C.c_int, [_P, _P, C.c_int, _P, _P, _P, _P]),
     "agx_fovea_flexible": (C.c_int, [_P, _P, C.c_int, _P, _P, _P, _P, _P, _P]),
 }

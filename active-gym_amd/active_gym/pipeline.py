@@ -143,6 +143,34 @@ class ObsPipeline:
         pc = self._chk(cmd, (self.num_envs,), torch.uint8, "cmd")
         nat.check(self._lib.agx_ingest_gray(self._ctx, ps, pc, self._stream()), self._ctx)
 
+    # ------------------------------------------------------------------ fused step (fixed kind)
+    def step_fixed(self, frames: torch.Tensor, cmd: torch.Tensor, action: Optional[torch.Tensor] = None,
+                   out: Optional[torch.Tensor] = None, loc_out: Optional[torch.Tensor] = None,
+                   mid_event: Optional[torch.cuda.Event] = None):
+        """ingest(frames, cmd) + fovea(action) in one ABI call (same results); returns (obs, fov_loc).
+        `mid_event` (a torch.cuda.Event that has been recorded once, so that its handle exists) is recorded
+        between the two launches."""
+        if self.kind != "fixed":
+            raise RuntimeError("step_fixed needs a pipeline of kind 'fixed'")
+        N = self.num_envs
+        pf = self._chk(frames, (N, 2, nat.RAW_H, nat.RAW_W, 3), torch.uint8, "frames")
+        pc = self._chk(cmd, (N,), torch.uint8, "cmd")
+        pa, dt = None, 0
+        if action is not None:
+            if action.dtype not in _DT:
+                raise TypeError(f"sensory action dtype {action.dtype} not supported (f32/f64/i32/i64)")
+            pa = self._chk(action, (N, 2), None, "action")
+            dt = _DT[action.dtype]
+        if out is None:
+            out = torch.empty(self.obs_shape, dtype=torch.float32, device=self.device)
+        po = self._chk(out, self.obs_shape, torch.float32, "out")
+        if loc_out is None:
+            loc_out = torch.empty((N, 2), dtype=torch.int32, device=self.device)
+        pl = self._chk(loc_out, (N, 2), torch.int32, "loc_out")
+        pe = C.c_void_p(mid_event.cuda_event) if mid_event is not None else None
+        nat.check(self._lib.agx_step_fixed(self._ctx, pf, pc, pa, dt, po, pl, pe, self._stream()), self._ctx)
+        return out, loc_out
+
     # ------------------------------------------------------------------ K0
     def observe_full(self, out: Optional[torch.Tensor] = None) -> torch.Tensor:
         if out is None:

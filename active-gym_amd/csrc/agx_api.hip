@@ -473,15 +473,8 @@ int64_t agx_algorithmic_bytes(const agx_ctx *ctx, int kernel_id) {
 }
 
 // ---------------------------------------------------------------- K1
-int agx_ingest(agx_ctx *ctx, const uint8_t *d_frames, const uint8_t *d_cmd, void *stream) {
-    if (!ctx) return AGX_E_INVALID;
-    if (!d_frames || !d_cmd) return fail(ctx, AGX_E_INVALID, "agx_ingest: null buffer");
+static IngestParams ingest_params(agx_ctx *ctx, const uint8_t *d_frames, const uint8_t *d_cmd) {
     const agx_config &c = ctx->cfg;
-    if (c.obs_h != c.obs_w)
-        return fail(ctx, AGX_E_INVALID,
-                    "agx_ingest: obs_size (%d,%d) is not square; the reference hands obs_size to cv2.resize as "
-                    "(width,height) and fails on non-square sizes (atari_env.py:74,126)", c.obs_h, c.obs_w);
-    DeviceGuard g(c.device);
     IngestParams p;
     p.frames = d_frames;
     p.cmd = d_cmd;
@@ -498,13 +491,30 @@ int agx_ingest(agx_ctx *ctx, const uint8_t *d_frames, const uint8_t *d_cmd, void
     p.y_mul = ctx->y_mul;
     p.y_add = ctx->y_add;
     p.y_shift = ctx->y_shift;
-    const int bands = (c.obs_h + ctx->band_rows - 1) / ctx->band_rows;
-    const size_t lds = sizeof(int4) * ctx->band_rows + sizeof(int2) * c.obs_w + (size_t)2 * ctx->band_rows * 2 * kRawW;
-    p.nbands = bands;
+    p.nbands = (c.obs_h + ctx->band_rows - 1) / ctx->band_rows;
     p.stamps = nullptr;
 #ifdef AGX_STAMPS
     if (const char *e = getenv("AGX_DBG_PTR")) p.stamps = reinterpret_cast<unsigned long long *>(strtoull(e, nullptr, 0));
 #endif
+    return p;
+}
+
+static size_t ingest_lds(const agx_ctx *ctx) {
+    return sizeof(int4) * ctx->band_rows + sizeof(int2) * ctx->cfg.obs_w + (size_t)2 * ctx->band_rows * 2 * kRawW;
+}
+
+int agx_ingest(agx_ctx *ctx, const uint8_t *d_frames, const uint8_t *d_cmd, void *stream) {
+    if (!ctx) return AGX_E_INVALID;
+    if (!d_frames || !d_cmd) return fail(ctx, AGX_E_INVALID, "agx_ingest: null buffer");
+    const agx_config &c = ctx->cfg;
+    if (c.obs_h != c.obs_w)
+        return fail(ctx, AGX_E_INVALID,
+                    "agx_ingest: obs_size (%d,%d) is not square; the reference hands obs_size to cv2.resize as "
+                    "(width,height) and fails on non-square sizes (atari_env.py:74,126)", c.obs_h, c.obs_w);
+    DeviceGuard g(c.device);
+    const IngestParams p = ingest_params(ctx, d_frames, d_cmd);
+    const int bands = p.nbands;
+    const size_t lds = ingest_lds(ctx);
     static const int pipe_parts = [] { const char *e = getenv("AGX_INGEST_PIPE"); return e ? atoi(e) : 0; }();
     // wave-private form: needs the affine row form, band_rows = 4 * RPW with RPW * ow/4 <= 64 lanes and
     // 2 frames * RPW rows * 40 pieces <= 240 (RPW <= 3)
@@ -666,6 +676,8 @@ static FovParams fov_params(agx_ctx *ctx, const void *d_action, int dt, const in
     p.per_h = c.per_h;
     p.per_w = c.per_w;
     p.buf1_floats = (int32_t)generic_buf1(c);
+    p.cmd = nullptr;
+    p.phase = 0;
     return p;
 }
 
@@ -697,6 +709,55 @@ int agx_fovea_fixed(agx_ctx *ctx, const void *d_action, int action_dtype, const 
         default: LAUNCH(AGX_OUT_RESIZE); break;
     }
 #undef LAUNCH
+    AGX_HIP(ctx, hipGetLastError());
+    ctx->cur_fov ^= 1;
+    return AGX_OK;
+}
+
+// ---------------------------------------------------------------- fused step (K1 + K2)
+int agx_step_fixed(agx_ctx *ctx, const uint8_t *d_frames, const uint8_t *d_cmd, const void *d_action, int action_dtype,
+                   float *d_obs, int32_t *d_fov_loc, void *mid_event, void *stream) {
+    if (!ctx) return AGX_E_INVALID;
+    const agx_config &c = ctx->cfg;
+    if (c.kind != AGX_KIND_FIXED) return fail(ctx, AGX_E_STATE, "agx_step_fixed on a context of kind %d", c.kind);
+    if (!d_frames || !d_cmd || !d_obs) return fail(ctx, AGX_E_INVALID, "agx_step_fixed: null buffer");
+    int rc = check_dt(ctx, d_action, action_dtype);
+    if (rc) return rc;
+    const bool headline = c.obs_h == 84 && c.obs_w == 84 && c.fov_h == 30 && c.fov_w == 30;
+    // The heterogeneous launch (ingest bands + fovea of the untouched slots in one grid, written slot after) is
+    // bit-identical and measured a tie at N=1024 (69.3 vs 67.9 us per step: it fills the ingest's drain but its
+    // second launch is one latency chain long), so the default is the two stand-alone launches.
+    static const bool fused = getenv("AGX_STEP_FUSED") != nullptr;              // tuning / testing knob
+    if (c.out_mode != AGX_OUT_RESIZE || ctx->ingest_t != 256 || !fused || c.obs_h != c.obs_w) {
+        // the two stand-alone launches, same results
+        rc = agx_ingest(ctx, d_frames, d_cmd, stream);
+        if (rc) return rc;
+        if (mid_event) AGX_HIP(ctx, hipEventRecord(static_cast<hipEvent_t>(mid_event), S(stream)));
+        return agx_fovea_fixed(ctx, d_action, action_dtype, nullptr, d_obs, d_fov_loc, stream);
+    }
+    DeviceGuard g(c.device);
+    const IngestParams pi = ingest_params(ctx, d_frames, d_cmd);
+    FovParams pf = fov_params(ctx, d_action, action_dtype, nullptr, nullptr, d_obs, d_fov_loc, nullptr);
+    pf.cmd = d_cmd;
+    pf.phase = 1;
+    pf.head = ctx->head[ctx->cur_head];                  // the head BEFORE this step's ingest
+    const size_t lds = std::max(ingest_lds(ctx), fixed_lds(c));
+    const dim3 grid1(pi.nbands + c.frame_stack, c.num_envs), grid2(1, c.num_envs), block(kThreads);
+    using GS = GeomS<84, 84, 30, 30>;
+    const GeomR gr{c.obs_h, c.obs_w, c.fov_h, c.fov_w};
+    if (headline)
+        hipLaunchKernelGGL((k_step_fixed<GS>), grid1, block, lds, S(stream), GS{}, pi, pf);
+    else
+        hipLaunchKernelGGL((k_step_fixed<GeomR>), grid1, block, lds, S(stream), gr, pi, pf);
+    AGX_HIP(ctx, hipGetLastError());
+    ctx->cur_head ^= 1;
+    if (mid_event) AGX_HIP(ctx, hipEventRecord(static_cast<hipEvent_t>(mid_event), S(stream)));
+    pf.phase = 2;
+    pf.head = ctx->head[ctx->cur_head];                  // the head AFTER the ingest
+    if (headline)
+        hipLaunchKernelGGL((k_step_fixed_tail<GS>), grid2, block, fixed_lds(c), S(stream), GS{}, pf);
+    else
+        hipLaunchKernelGGL((k_step_fixed_tail<GeomR>), grid2, block, fixed_lds(c), S(stream), gr, pf);
     AGX_HIP(ctx, hipGetLastError());
     ctx->cur_fov ^= 1;
     return AGX_OK;

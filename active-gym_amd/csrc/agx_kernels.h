@@ -188,10 +188,7 @@ struct IngestParams {
 // one aligned u16, so the bilinear taps of an output pixel are two ds_read_u16.
 // Measured floor of this access shape with no arithmetic at all: ~30 us at N=1024 (tools/membench.hip).
 template <int T>
-__global__ __launch_bounds__(T) void k_ingest(IngestParams p) {
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    const int n = blockIdx.y;
-    const int band = blockIdx.x;
+__device__ __forceinline__ void ingest_band(const IngestParams &p, const int band, const int n, unsigned char *smem) {
     const int tid = threadIdx.x;
     AGX_STAMP(0);
     const int BR = p.band_rows;
@@ -353,6 +350,12 @@ __global__ __launch_bounds__(T) void k_ingest(IngestParams p) {
             for (int s = 0; s < p.fs - 1; ++s) *reinterpret_cast<uint32_t *>(env + (s * fsz + off)) = 0u;
     }
     AGX_STAMP(4);
+}
+
+template <int T>
+__global__ __launch_bounds__(T) void k_ingest(IngestParams p) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    ingest_band<T>(p, blockIdx.x, blockIdx.y, smem);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -800,6 +803,13 @@ struct FovParams {
     int32_t antialias;
     int32_t per_h, per_w;
     int32_t buf1_floats;        // generic kernels: size of the second LDS buffer (multiple of 4)
+    // fused step (agx_step_fixed): the fovea work of one step is split around the ingest it rides with
+    //   phase 0: stand-alone launch, `head` is the ring head after the ingest
+    //   phase 1: same launch as the ingest: `head` is the head BEFORE it; only slots the ingest does not
+    //            touch are processed (sl != written slot, env not cleared)
+    //   phase 2: after the ingest: the written slot (all slots of a cleared env)
+    const uint8_t *cmd;         // ingest command bytes (phases 1 and 2)
+    int32_t phase;
 };
 
 // Raw inputs of the fov_loc update.  Kept separate from the arithmetic so that a kernel can issue
@@ -909,13 +919,29 @@ __device__ __forceinline__ void store_obs(T4 *dst, const T4 &v) {
 // (ablation of the previous serial version at N=1024: loc chain 5.8 us, loc-dependent window load
 //  6.3 us, H pass with a tap load per iteration 7.3 us, row-tap loads 2.1 us of a 32.7 us launch.)
 template <class G, int MODE>
-__global__ __launch_bounds__(kThreads) void k_fovea_fixed(G g, FovParams p) {
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    const int sl = blockIdx.x, n = blockIdx.y, tid = threadIdx.x;
+__device__ __forceinline__ void fovea_fixed_body(const G g, const FovParams &p, const int sl, const int n,
+                                                 unsigned char *smem) {
+    const int tid = threadIdx.x;
     const int oh = g.oh(), ow = g.ow(), fh = g.fh(), fw = g.fw();
     if (p.mask && !p.mask[n]) {
         if (sl == 0 && tid < 2) p.loc_out[2 * n + tid] = p.loc_in[2 * n + tid];
         return;
+    }
+    int head_fixup = 0;                      // what to add to p.head[n] to get the post-ingest head
+    if (p.phase != 0) {
+        const uint32_t cmd = uniform_load_u8(p.cmd + n);
+        const bool skip = (cmd & AGX_CMD_SKIP) != 0, clear = (cmd & AGX_CMD_CLEAR) != 0 && !skip;
+        const int h = uniform_load_i32(p.head + n);
+        // slot the ingest writes: the pre-ingest head (fs-1 after a clear, which also zeroes the others)
+        int wslot;
+        if (p.phase == 1) {
+            wslot = h;
+            head_fixup = skip ? 0 : (clear ? -h : (h + 1 == p.fs ? 1 - p.fs : 1));
+        } else {
+            wslot = skip ? h : (h == 0 ? p.fs - 1 : h - 1);
+        }
+        const bool touched = clear || sl == wslot;
+        if ((p.phase == 1) == touched) return;            // phase 1 takes the untouched slots, phase 2 the rest
     }
     // LDS carve: lut[256] | raw[oh*ow] u8 | ytab[oh] | H[fh][ow]
     float *lut = reinterpret_cast<float *>(smem);
@@ -941,7 +967,7 @@ __global__ __launch_bounds__(kThreads) void k_fovea_fixed(G g, FovParams p) {
         yt = *reinterpret_cast<const int4 *>(p.ytab + min(tid, oh - 1));
     }
     const LocIn lin = load_loc_inputs(p, n);
-    const int head = p.head[n];
+    const int head = p.head[n] + head_fixup;
     lut[tid] = unit((uint32_t)tid);
     int r, c;
     compute_loc(p, lin, oh - fh, ow - fw, r, c);
@@ -1023,6 +1049,54 @@ __global__ __launch_bounds__(kThreads) void k_fovea_fixed(G g, FovParams p) {
         o.w = t.a * a.w + t.b * b.w;
         store_obs(&out4[q], o);
     }
+}
+
+template <class G, int MODE>
+__global__ __launch_bounds__(kThreads) void k_fovea_fixed(G g, FovParams p) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    fovea_fixed_body<G, MODE>(g, p, blockIdx.x, blockIdx.y, smem);
+}
+
+// Fused step, second launch: grid = (1, N).  One workgroup per env processes the ring slot the ingest
+// has just written; for the rare cleared env (full reset: every slot changed) it walks all of them.
+template <class G>
+__global__ __launch_bounds__(kThreads) void k_step_fixed_tail(G g, FovParams p) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int n = blockIdx.y;
+    if (p.mask && !p.mask[n]) return;        // (the fused step never passes a mask; kept for symmetry)
+    const uint32_t cmd = uniform_load_u8(p.cmd + n);
+    const bool skip = (cmd & AGX_CMD_SKIP) != 0, clear = (cmd & AGX_CMD_CLEAR) != 0 && !skip;
+    const int h = uniform_load_i32(p.head + n);
+    const int wslot = skip ? h : (h == 0 ? p.fs - 1 : h - 1);
+    FovParams q = p;
+    q.phase = 0;                             // `head` is already the post-ingest head
+    if (!clear) {
+        fovea_fixed_body<G, AGX_OUT_RESIZE>(g, q, wslot, n, smem);
+        // slot 0 is the one that publishes fov_loc; it ran in the first launch unless it is the written slot
+        return;
+    }
+    for (int sl = 0; sl < p.fs; ++sl) {
+        if (sl) __syncthreads();             // the LDS image of the previous slot has been consumed
+        fovea_fixed_body<G, AGX_OUT_RESIZE>(g, q, sl, n, smem);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Fused step, first launch: grid = (bands + fs, N), block = 256.  Workgroups x < bands ingest band x
+// of env n; workgroups x >= bands run the resize_to_full fovea of ring slot x - bands, but only for
+// the slots this step's ingest does not touch (phase 1).  The two kinds of workgroup are independent
+// (disjoint ring slots, double-buffered head / fov_loc), so the store-bound fovea work fills the
+// issue slots and the drain of the load/ALU-bound ingest (K1 alone: CUs run dry for its last 9 us).
+// The written slot follows in a second, small launch of k_fovea_fixed with phase 2.
+// ---------------------------------------------------------------------------------------------
+template <class G>
+__global__ __launch_bounds__(kThreads) void k_step_fixed(G g, IngestParams pi, FovParams pf) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int x = blockIdx.x, n = blockIdx.y;
+    if (x < pi.nbands)
+        ingest_band<kThreads>(pi, x, n, smem);
+    else
+        fovea_fixed_body<G, AGX_OUT_RESIZE>(g, pf, x - pi.nbands, n, smem);
 }
 
 // ---------------------------------------------------------------------------------------------

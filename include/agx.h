@@ -171,6 +171,15 @@ AGX_API int agx_set_fov_state(agx_ctx *ctx, const int32_t *d_fov_loc, const int3
 AGX_API int agx_fovea_fixed(agx_ctx *ctx, const void *d_action, int action_dtype, const uint8_t *d_mask,
                     float *d_obs, int32_t *d_fov_loc, void *stream);
 
+/* ---- fused step: agx_ingest followed by agx_fovea_fixed (d_mask = NULL), same results ----------
+ * One whole `FixedFovealEnv.step` image path (fov_env.py:209-221 over atari_env.py:119-148) for all envs.
+ * With AGX_STEP_FUSED=1 in the environment (resize_to_full contexts) the fovea work of the ring slots this
+ * step's ingest does not touch rides in the ingest launch (heterogeneous workgroups) and the written slot
+ * follows in a second small launch; by default it issues the two stand-alone launches (measured equal).
+ * mid_event: optional hipEvent_t (may be NULL) recorded on `stream` between the two launches (profiling). */
+AGX_API int agx_step_fixed(agx_ctx *ctx, const uint8_t *d_frames, const uint8_t *d_cmd, const void *d_action,
+                           int action_dtype, float *d_obs, int32_t *d_fov_loc, void *mid_event, void *stream);
+
 /* ---- K3: FixedFovealPeripheralEnv._get_fov_state (fov_env.py:375-388) ---
  * whole stack squeezed to peripheral_res and expanded back, full-res fovea pasted. */
 AGX_API int agx_fovea_peripheral(agx_ctx *ctx, const void *d_action, int action_dtype, const uint8_t *d_mask,

@@ -491,3 +491,43 @@ def test_large_and_odd_batches(dev):
             newest = p.stack_u8()[:, -1].cpu().numpy()
             for i in range(N):
                 assert np.array_equal(newest[i], np.maximum(O.get_state_u8(frames[i, 0], (84, 84)), O.get_state_u8(frames[i, 1], (84, 84))))
+
+
+# ---------------------------------------------------------------- fused step == ingest + fovea
+@pytest.mark.parametrize("geom", ["headline", "generic"])
+def test_step_fixed_equals_separate_calls(dev, geom, monkeypatch):
+    monkeypatch.setenv("AGX_STEP_FUSED", "1")       # read once per process by the library: set before the first call
+    N, fs = 37, 4
+    rng = np.random.default_rng(77)
+    fov = (30, 30) if geom == "headline" else (26, 34)
+    kw = dict(num_envs=N, kind="fixed", obs_size=(84, 84), fov_size=fov, frame_stack=fs, resize_to_full=True,
+              fov_init_loc=(3, 4), sensory_action_mode="relative", sensory_action_space=(-12.0, 12.0))
+    a, b = _pipe(**kw), _pipe(**kw)
+    ring = O.RingOracle(N, fs, (84, 84))
+    orcs = [O.FixedFovealOracle(obs_size=(84, 84), fov_size=fov, fov_init_loc=(3, 4), sensory_action_mode="relative",
+                                sensory_action_space=(-12.0, 12.0), resize_to_full=True) for _ in range(N)]
+    for step in range(9):
+        frames = _t(rng.integers(0, 256, (N, 2, 210, 160, 3), dtype=np.uint8), dev)
+        nvalid = rng.integers(0, 3, N)
+        clear = (rng.random(N) < 0.25).astype(np.uint8)
+        skip = (rng.random(N) < 0.2).astype(np.uint8)
+        nvalid[clear == 1] = 1
+        cmd = _t((nvalid | clear * 4 | skip * 8).astype(np.uint8), dev)
+        act_np = rng.uniform(-15, 15, (N, 2))
+        act = _t(act_np, dev)
+        oa, la = a.step_fixed(frames, cmd, act)
+        b.ingest(frames, cmd)
+        ob, lb = b.fovea(act)
+        assert torch.equal(la, lb), step
+        assert torch.equal(oa, ob), f"step {step}: fused and separate launches must agree bit for bit"
+        assert torch.equal(a.stack_u8(), b.stack_u8())
+        ring.ingest(frames.cpu().numpy(), nvalid, clear=clear, skip=skip)
+        full = ring.full_state()
+        oa_np, la_np = oa.cpu().numpy(), la.cpu().numpy()
+        for i in range(0, N, 5):
+            want = orcs[i].step(full[i], act_np[i])
+            assert np.array_equal(la_np[i], orcs[i].fov_loc)
+            np.testing.assert_allclose(oa_np[i], want, rtol=0, atol=FLOAT_TOL)
+        for i in range(N):
+            if i % 5:
+                orcs[i].update_loc(act_np[i])
