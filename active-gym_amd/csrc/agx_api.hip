@@ -678,6 +678,10 @@ static FovParams fov_params(agx_ctx *ctx, const void *d_action, int dt, const in
     p.buf1_floats = (int32_t)generic_buf1(c);
     p.cmd = nullptr;
     p.phase = 0;
+    p.stamps = nullptr;
+#ifdef AGX_STAMPS
+    if (const char *e = getenv("AGX_DBG_PTR2")) p.stamps = reinterpret_cast<unsigned long long *>(strtoull(e, nullptr, 0));
+#endif
     return p;
 }
 

@@ -810,6 +810,7 @@ struct FovParams {
     //   phase 2: after the ingest: the written slot (all slots of a cleared env)
     const uint8_t *cmd;         // ingest command bytes (phases 1 and 2)
     int32_t phase;
+    unsigned long long *stamps; // diagnostic builds only (AGX_STAMPS)
 };
 
 // Raw inputs of the fov_loc update.  Kept separate from the arithmetic so that a kernel can issue
@@ -922,6 +923,9 @@ template <class G, int MODE>
 __device__ __forceinline__ void fovea_fixed_body(const G g, const FovParams &p, const int sl, const int n,
                                                  unsigned char *smem) {
     const int tid = threadIdx.x;
+    constexpr int T = kThreads;
+    (void)T;
+    AGX_STAMP(0);
     const int oh = g.oh(), ow = g.ow(), fh = g.fh(), fw = g.fw();
     if (p.mask && !p.mask[n]) {
         if (sl == 0 && tid < 2) p.loc_out[2 * n + tid] = p.loc_in[2 * n + tid];
@@ -989,7 +993,9 @@ __device__ __forceinline__ void fovea_fixed_body(const G g, const FovParams &p, 
         if (tid < oh) *reinterpret_cast<int4 *>(ytab_s + tid) = yt;
         for (int i = tid + kThreads; i < oh; i += kThreads) ytab_s[i] = p.ytab[i];
     }
+    AGX_STAMP(1);
     __syncthreads();
+    AGX_STAMP(2);
 
     const unsigned char *win = raw + r * ow + c;                      // window origin inside the frame
     if (MODE == AGX_OUT_RAW) {
@@ -1034,6 +1040,7 @@ __device__ __forceinline__ void fovea_fixed_body(const G g, const FovParams &p, 
         }
     }
     __syncthreads();
+    AGX_STAMP(3);
     // ---- phase D
     const float4 *H4 = reinterpret_cast<const float4 *>(H);
 #pragma unroll 7
@@ -1049,6 +1056,7 @@ __device__ __forceinline__ void fovea_fixed_body(const G g, const FovParams &p, 
         o.w = t.a * a.w + t.b * b.w;
         store_obs(&out4[q], o);
     }
+    AGX_STAMP(4);
 }
 
 template <class G, int MODE>

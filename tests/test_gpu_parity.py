@@ -531,3 +531,47 @@ def test_step_fixed_equals_separate_calls(dev, geom, monkeypatch):
         for i in range(N):
             if i % 5:
                 orcs[i].update_loc(act_np[i])
+
+
+# ---------------------------------------------------------------- streams, several contexts, lifetime
+def test_non_default_stream_and_interleaved_contexts(dev):
+    N = 12
+    rng = np.random.default_rng(5)
+    kw = dict(num_envs=N, kind="fixed", obs_size=(84, 84), fov_size=(30, 30), frame_stack=2, resize_to_full=True)
+    a, b = _pipe(**kw), _pipe(**kw)
+    fa = _t(rng.integers(0, 256, (N, 2, 210, 160, 3), dtype=np.uint8), dev)
+    fb = _t(rng.integers(0, 256, (N, 2, 210, 160, 3), dtype=np.uint8), dev)
+    cmd = torch.full((N,), 2, dtype=torch.uint8, device=dev)
+    act = _t(rng.uniform(0, 54, (N, 2)).astype(np.float32), dev)
+    ref = _pipe(**kw)
+    ref.ingest(fa, cmd)
+    want_a, _ = ref.fovea(act)
+    ref2 = _pipe(**kw)
+    ref2.ingest(fb, cmd)
+    want_b, _ = ref2.fovea(act)
+    torch.cuda.synchronize()
+    s1, s2 = torch.cuda.Stream(device=dev), torch.cuda.Stream(device=dev)
+    with torch.cuda.stream(s1):
+        a.ingest(fa, cmd)
+    with torch.cuda.stream(s2):
+        b.ingest(fb, cmd)
+    with torch.cuda.stream(s1):
+        oa, _ = a.fovea(act)
+    with torch.cuda.stream(s2):
+        ob, _ = b.fovea(act)
+    s1.synchronize()
+    s2.synchronize()
+    assert torch.equal(oa, want_a) and torch.equal(ob, want_b)
+
+
+def test_create_destroy_does_not_leak(dev):
+    torch.cuda.synchronize()
+    free0, _ = torch.cuda.mem_get_info(dev)
+    for kind, extra in (("fixed", dict(resize_to_full=True)), ("peripheral", dict(peripheral_res=(20, 20))),
+                        ("flexible", dict(resize_to_full=True)), ("base", dict())):
+        for _ in range(6):
+            p = _pipe(num_envs=512, kind=kind, obs_size=(84, 84), fov_size=(30, 30), frame_stack=4, **extra)
+            p.close()
+    torch.cuda.synchronize()
+    free1, _ = torch.cuda.mem_get_info(dev)
+    assert free0 - free1 < 64 << 20, f"leaked {(free0 - free1) >> 20} MiB"

@@ -5,8 +5,10 @@ sys.path[:0] = [os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__f
 import numpy as np, torch
 dev = torch.device("cuda:0")
 N = 1024
-st = torch.zeros((N * 7 * 4, 8), dtype=torch.int64, device=dev)
-os.environ["AGX_DBG_PTR"] = str(st.data_ptr())
+KERNEL = sys.argv[1] if len(sys.argv) > 1 else "ingest"
+WGS = N * 7 if KERNEL == "ingest" else N * 4
+st = torch.zeros((WGS * 4, 8), dtype=torch.int64, device=dev)
+os.environ["AGX_DBG_PTR" if KERNEL == "ingest" else "AGX_DBG_PTR2"] = str(st.data_ptr())
 from active_gym import ObsPipeline
 p = ObsPipeline(num_envs=N, kind="fixed", fov_size=(30, 30), resize_to_full=True, device=dev)
 g = torch.Generator(device=dev); g.manual_seed(0)
@@ -20,7 +22,7 @@ torch.cuda.synchronize()
 s = st.cpu().numpy()
 cyc = s[:, :5].astype(np.float64)
 d = np.diff(cyc, axis=1)
-for i, nme in enumerate(["issue+cmd wait", "lum+LDS write", "barrier wait", "phase2+store"]):
+for i, nme in enumerate(["issue+cmd wait", "lum+LDS write", "barrier wait", "phase2+store"] if KERNEL == "ingest" else ["loads->LDS image", "barrier wait", "H pass+barrier", "lerp+stores"]):
     print(f"{nme:16s} mean {d[:, i].mean():9.0f}  p50 {np.median(d[:, i]):9.0f}  p90 {np.percentile(d[:, i], 90):9.0f} cycles")
 life_c = cyc[:, 4] - cyc[:, 0]
 rt0, rt1 = s[:, 6].astype(np.float64), s[:, 7].astype(np.float64)          # 100 MHz constant clock
