@@ -1065,6 +1065,104 @@ __global__ __launch_bounds__(kThreads) void k_fovea_fixed(G g, FovParams p) {
     fovea_fixed_body<G, MODE>(g, p, blockIdx.x, blockIdx.y, smem);
 }
 
+// ---------------------------------------------------------------------------------------------
+// K2, two slots per workgroup (resize_to_full, stand-alone launch): grid = (fs/2, N), block = 256.
+// The occupancy timeline of the one-slot form shows two synchronized rounds of workgroups, each wave
+// spending 54 % of its life on the load chain.  Here a workgroup requests BOTH of its frames up front
+// and keeps the second in registers while the first goes LDS -> H -> stores, so the second frame's load
+// latency is hidden and the whole launch is resident at once (2048 workgroups x 4 waves at N=1024).
+// ---------------------------------------------------------------------------------------------
+template <class G>
+__global__ __launch_bounds__(kThreads) void k_fovea_fixed2(G g, FovParams p) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int n = blockIdx.y, tid = threadIdx.x;
+    const int oh = g.oh(), ow = g.ow(), fh = g.fh(), fw = g.fw();
+    const int sl0 = 2 * blockIdx.x;
+    if (p.mask && !p.mask[n]) {
+        if (sl0 == 0 && tid < 2) p.loc_out[2 * n + tid] = p.loc_in[2 * n + tid];
+        return;
+    }
+    float *lut = reinterpret_cast<float *>(smem);
+    unsigned char *raw = smem + 1024;
+    const int fbytes = oh * ow, fwords = fbytes >> 2;
+    const int raw_pad = (fbytes + 15) & ~15;
+    Tap *ytab_s = reinterpret_cast<Tap *>(raw + raw_pad);
+    float *H = reinterpret_cast<float *>(ytab_s + oh);
+    constexpr int kFW = 7;
+    uint32_t fa[kFW], fb[kFW];
+    const uint32_t *src0 = reinterpret_cast<const uint32_t *>(p.ring + ((size_t)n * p.fs + sl0) * (size_t)fbytes);
+    const uint32_t *src1 = src0 + fwords;
+#pragma unroll
+    for (int k = 0; k < kFW; ++k) fa[k] = src0[min(tid + k * kThreads, fwords - 1)];
+#pragma unroll
+    for (int k = 0; k < kFW; ++k) fb[k] = src1[min(tid + k * kThreads, fwords - 1)];
+    const int xcol = tid % ow, yb = tid / ow;
+    const int4 xt = *reinterpret_cast<const int4 *>(p.xtab + xcol);
+    const int4 yt = *reinterpret_cast<const int4 *>(p.ytab + min(tid, oh - 1));
+    const LocIn lin = load_loc_inputs(p, n);
+    const int head = p.head[n];
+    lut[tid] = unit((uint32_t)tid);
+    int r, c;
+    compute_loc(p, lin, oh - fh, ow - fw, r, c);
+    if (sl0 == 0 && tid == 0) {
+        p.loc_out[2 * n] = r;
+        p.loc_out[2 * n + 1] = c;
+        if (p.user_loc) {
+            p.user_loc[2 * n] = r;
+            p.user_loc[2 * n + 1] = c;
+        }
+    }
+    if (tid < oh) *reinterpret_cast<int4 *>(ytab_s + tid) = yt;
+    for (int i = tid + kThreads; i < oh; i += kThreads) ytab_s[i] = p.ytab[i];
+    const int ow4 = ow >> 2;
+    const int rstep = kThreads / ow;
+    const float wa = __int_as_float(xt.z), wb = __int_as_float(xt.w);
+    const float4 *H4 = reinterpret_cast<const float4 *>(H);
+#pragma unroll
+    for (int half = 0; half < 2; ++half) {
+        if (half) __syncthreads();                                    // raw / H of the first frame are consumed
+#pragma unroll
+        for (int k = 0; k < kFW; ++k)
+            if (tid + k * kThreads < fwords) reinterpret_cast<uint32_t *>(raw)[tid + k * kThreads] = half ? fb[k] : fa[k];
+        if (kFW * kThreads < fwords) {
+            const uint32_t *src = half ? src1 : src0;
+            for (int i = tid + kFW * kThreads; i < fwords; i += kThreads) reinterpret_cast<uint32_t *>(raw)[i] = src[i];
+        }
+        __syncthreads();
+        const unsigned char *win = raw + r * ow + c;
+        if (rstep > 0) {
+            if (yb < rstep) {
+                const unsigned char *c0 = win + xt.x, *c1 = win + xt.y;
+#pragma unroll 10
+                for (int y = yb; y < fh; y += rstep) H[y * ow + xcol] = wa * lut[c0[y * ow]] + wb * lut[c1[y * ow]];
+            }
+        } else {
+            for (int i = tid; i < fh * ow; i += kThreads) {
+                const int y = i / ow, x = i - y * ow;
+                const Tap t = p.xtab[x];
+                H[i] = t.a * lut[win[y * ow + t.lo]] + t.b * lut[win[y * ow + t.aux]];
+            }
+        }
+        __syncthreads();
+        int j = sl0 + half - head;
+        if (j < 0) j += p.fs;
+        float4 *out4 = reinterpret_cast<float4 *>(p.obs) + ((size_t)n * p.fs + j) * (size_t)(oh * ow4);
+#pragma unroll 7
+        for (int q = tid; q < oh * ow4; q += kThreads) {
+            const int row = q / ow4, x4 = q - row * ow4;
+            const Tap t = ytab_s[row];
+            const float4 a = H4[t.lo * ow4 + x4];
+            const float4 b = H4[t.aux * ow4 + x4];
+            float4 o;
+            o.x = t.a * a.x + t.b * b.x;
+            o.y = t.a * a.y + t.b * b.y;
+            o.z = t.a * a.z + t.b * b.z;
+            o.w = t.a * a.w + t.b * b.w;
+            store_obs(&out4[q], o);
+        }
+    }
+}
+
 // Fused step, second launch: grid = (1, N).  One workgroup per env processes the ring slot the ingest
 // has just written; for the rare cleared env (full reset: every slot changed) it walks all of them.
 template <class G>
