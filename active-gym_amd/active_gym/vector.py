@@ -103,9 +103,18 @@ class AtariVecEnv:
         self._ev_rcopy = torch.cuda.Event()
         self._h_cmd = torch.empty((self.num_envs,), dtype=torch.uint8, pin_memory=True)
         self._d_cmd = torch.empty((self.num_envs,), dtype=torch.uint8, device=self.device)
-        self.runner = AtariHostRunner(args, self.num_envs, frames=self._h_frames.numpy(),
-                                      workers=getattr(args, "num_workers", None), noop_fn=noop_fn,
-                                      env_offset=env_offset)
+        src = getattr(args, "frame_source", "ale")
+        if isinstance(src, str) and src.startswith("native"):
+            # C++ thread-per-core runner (libagx_runner.so): "native" = built-in scripted emulator,
+            # "native:ale" = real ALE through atari_py's libale_c.so
+            from .native_runner import NativeHostRunner
+            self.runner = NativeHostRunner(args, self.num_envs, frames=self._h_frames.numpy(),
+                                           workers=getattr(args, "num_workers", None), noop_fn=noop_fn,
+                                           env_offset=env_offset, backend="ale_c" if src == "native:ale" else "scripted")
+        else:
+            self.runner = AtariHostRunner(args, self.num_envs, frames=self._h_frames.numpy(),
+                                          workers=getattr(args, "num_workers", None), noop_fn=noop_fn,
+                                          env_offset=env_offset)
 
         # spaces (reference atari_env.py:69-70, fov_env.py:125-142,243)
         n_act = self.runner.num_actions
@@ -247,8 +256,21 @@ class AtariVecEnv:
         if isinstance(motor, torch.Tensor):
             motor = motor.detach().cpu().numpy()
         self._ev_copy.synchronize()             # the previous step's screens have left the pinned buffer
-        reward, done, cmd, raw = self.runner.step(motor)
-        self._upload(cmd)
+        chunk = int(getattr(self.args, "h2d_chunk_envs", 0) or 0)
+        if chunk > 0 and hasattr(self.runner, "step_begin"):
+            # native runner: chunk c's screens cross PCIe while chunk c+1 is still emulating
+            nc = self.runner.step_begin(motor, chunk)
+            for c in range(nc):
+                self.runner.step_wait(c)
+                lo, hi = c * chunk, min(n, (c + 1) * chunk)
+                self._d_frames[lo:hi].copy_(self._h_frames[lo:hi], non_blocking=True)
+            reward, done, cmd, raw = self.runner.step_finish()
+            self._h_cmd.numpy()[:] = cmd
+            self._d_cmd.copy_(self._h_cmd, non_blocking=True)
+            self._ev_copy.record()
+        else:
+            reward, done, cmd, raw = self.runner.step(motor)
+            self._upload(cmd)
         self.pipe.ingest(self._d_frames, self._d_cmd)
         obs = self._observe(sens, stype)
         self.ep_len += 1

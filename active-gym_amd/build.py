@@ -46,6 +46,26 @@ def build(force=False, verbose=False, extra=()):
     return OUT
 
 
+RUNNER_SRC = os.path.join(HERE, "csrc", "agx_runner.cpp")
+RUNNER_OUT = os.path.join(OUT_DIR, "libagx_runner.so")
+
+
+def build_runner(force=False, verbose=False):
+    """The native host runner (include/agx_runner.h): plain C++17 + pthreads, no GPU code."""
+    deps = [RUNNER_SRC, os.path.join(REPO, "include", "agx_runner.h")]
+    if not force and os.path.exists(RUNNER_OUT) and all(os.path.getmtime(RUNNER_OUT) >= os.path.getmtime(d) for d in deps):
+        return RUNNER_OUT
+    os.makedirs(OUT_DIR, exist_ok=True)
+    cmd = ["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-fvisibility=hidden", "-Wall", "-I", os.path.join(REPO, "include"),
+           RUNNER_SRC, "-o", RUNNER_OUT + ".tmp", "-pthread", "-ldl"]
+    if verbose:
+        print(" ".join(cmd))
+    subprocess.run(cmd, check=True)
+    os.replace(RUNNER_OUT + ".tmp", RUNNER_OUT)
+    return RUNNER_OUT
+
+
 if __name__ == "__main__":
     extra = [a for a in sys.argv[1:] if a.startswith("-") and a not in ("-f", "-v")]
     print(build(force="-f" in sys.argv, verbose=True, extra=extra))
+    print(build_runner(force="-f" in sys.argv, verbose=True))

@@ -1,0 +1,438 @@
+// agx_runner.cpp — native host runner (include/agx_runner.h).  Plain C++17 + pthreads, no GPU code.
+#include "agx_runner.h"
+
+#include <dlfcn.h>
+
+#include <algorithm>
+#include <atomic>
+#include <condition_variable>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <functional>
+#include <memory>
+#include <mutex>
+#include <string>
+#include <thread>
+#include <vector>
+
+namespace {
+
+constexpr int kH = 210, kW = 160, kFrameBytes = kH * kW * 3;
+constexpr uint8_t kCmdClear = 0x04, kCmdSkip = 0x08;
+
+struct Emulator {
+    virtual ~Emulator() = default;
+    virtual int act(int action) = 0;          // returns the reward of one frame
+    virtual bool game_over() = 0;
+    virtual int lives() = 0;
+    virtual void reset_game() = 0;
+    virtual void screen_rgb(uint8_t *out) = 0; // [210][160][3]
+    virtual std::vector<int> minimal_actions() = 0;
+};
+
+// ---- "scripted": splitmix64 event script, arithmetic screens; mirrored by tests/lcg_ale.py ----------------
+struct ScriptedEmu final : Emulator {
+    uint64_t s, seed;
+    int n_actions, start_lives, p_life, p_over;
+    int lives_ = 0, frame = 0, episode = 0;
+    bool over = false;
+    ScriptedEmu(uint64_t seed_, int na, int lv, int pl, int po)
+        : s(seed_ * 0x9E3779B97F4A7C15ull + 0x1234567ull), seed(seed_), n_actions(na), start_lives(lv), p_life(pl), p_over(po) {
+        lives_ = lv;
+    }
+    uint64_t rnd() {
+        s += 0x9E3779B97F4A7C15ull;
+        uint64_t z = s;
+        z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+        z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+        return z ^ (z >> 31);
+    }
+    int act(int) override {
+        ++frame;
+        const uint64_t u0 = rnd(), u1 = rnd(), u2 = rnd();
+        int reward = 0;
+        if (u0 % 100 < 15) reward = (int)(rnd() % 10) - 2;
+        if (!over) {
+            if ((int)(u1 % 1000) < p_life) {
+                if (--lives_ <= 0) {
+                    lives_ = 0;
+                    over = true;
+                }
+            }
+            if ((int)(u2 % 1000) < p_over) over = true;
+        }
+        return reward;
+    }
+    bool game_over() override { return over; }
+    int lives() override { return lives_; }
+    void reset_game() override {
+        lives_ = start_lives;
+        over = false;
+        ++episode;
+        frame = 0;
+    }
+    void screen_rgb(uint8_t *out) override {
+        const uint32_t K = (uint32_t)((seed * 1000003ull + (uint64_t)episode * 7919ull + (uint64_t)frame * 31ull) & 0xFFFFu);
+        for (int y = 0; y < kH; ++y)
+            for (int x = 0; x < kW; ++x) {
+                const uint32_t base = (uint32_t)(y * 7 + x * 13) + K * 3u + (uint32_t)((y * x) >> 4);
+                uint8_t *p = out + ((size_t)y * kW + x) * 3;
+                p[0] = (uint8_t)(base & 0xFF);
+                p[1] = (uint8_t)((base + 29u) & 0xFF);
+                p[2] = (uint8_t)((base + 58u + (K >> 3)) & 0xFF);
+            }
+    }
+    std::vector<int> minimal_actions() override {
+        std::vector<int> v(n_actions);
+        for (int i = 0; i < n_actions; ++i) v[i] = i;
+        return v;
+    }
+};
+
+// ---- "ale_c": atari_py's C wrapper, dlopen'ed ------------------------------------------------------------
+struct AleApi {
+    void *lib = nullptr;
+    void *(*ALE_new)() = nullptr;
+    void (*ALE_del)(void *) = nullptr;
+    void (*setInt)(void *, const char *, int) = nullptr;
+    void (*setFloat)(void *, const char *, float) = nullptr;
+    void (*setBool)(void *, const char *, bool) = nullptr;
+    void (*loadROM)(void *, const char *) = nullptr;
+    int (*act)(void *, int) = nullptr;
+    bool (*game_over)(void *) = nullptr;
+    void (*reset_game)(void *) = nullptr;
+    int (*lives)(void *) = nullptr;
+    int (*getMinimalActionSize)(void *) = nullptr;
+    void (*getMinimalActionSet)(void *, int *) = nullptr;
+    void (*getScreenRGB)(void *, unsigned char *) = nullptr;
+    std::string load(const char *path) {
+        lib = dlopen(path, RTLD_NOW | RTLD_LOCAL);
+        if (!lib) return std::string("dlopen failed: ") + dlerror();
+#define SYM(name)                                                              \
+    name = reinterpret_cast<decltype(name)>(dlsym(lib, #name));                \
+    if (!name) return std::string("libale_c symbol missing: ") + #name;
+        SYM(ALE_new) SYM(ALE_del) SYM(setInt) SYM(setFloat) SYM(setBool) SYM(loadROM) SYM(act) SYM(game_over)
+        SYM(reset_game) SYM(lives) SYM(getMinimalActionSize) SYM(getMinimalActionSet) SYM(getScreenRGB)
+#undef SYM
+        return "";
+    }
+};
+
+struct AleEmu final : Emulator {
+    const AleApi *api;
+    void *ale;
+    AleEmu(const AleApi *a, const char *rom, int seed, int max_frames) : api(a), ale(a->ALE_new()) {
+        api->setInt(ale, "random_seed", seed);                       // atari_env.py:45-50
+        api->setInt(ale, "max_num_frames_per_episode", max_frames);
+        api->setFloat(ale, "repeat_action_probability", 0.f);
+        api->setInt(ale, "frame_skip", 0);
+        api->setBool(ale, "color_averaging", false);
+        api->loadROM(ale, rom);
+    }
+    ~AleEmu() override { api->ALE_del(ale); }
+    int act(int a) override { return api->act(ale, a); }
+    bool game_over() override { return api->game_over(ale); }
+    int lives() override { return api->lives(ale); }
+    void reset_game() override { api->reset_game(ale); }
+    void screen_rgb(uint8_t *out) override { api->getScreenRGB(ale, out); }
+    std::vector<int> minimal_actions() override {
+        std::vector<int> v(api->getMinimalActionSize(ale));
+        api->getMinimalActionSet(ale, v.data());
+        return v;
+    }
+};
+
+// ---- a small persistent thread pool: start(fn) calls fn(worker, nworkers) on every worker, wait() joins ---
+class Pool {
+  public:
+    explicit Pool(int n) : n_(n) {
+        for (int i = 0; i < n_; ++i) threads_.emplace_back([this, i] { loop(i); });
+    }
+    ~Pool() {
+        wait();
+        {
+            std::lock_guard<std::mutex> l(m_);
+            stop_ = true;
+            ++gen_;
+        }
+        cv_.notify_all();
+        for (auto &t : threads_) t.join();
+    }
+    int size() const { return n_; }
+    bool busy() {
+        std::lock_guard<std::mutex> l(m_);
+        return pending_ != 0;
+    }
+    void start(std::function<void(int, int)> fn) {
+        wait();
+        {
+            std::lock_guard<std::mutex> l(m_);
+            fn_ = std::move(fn);
+            pending_ = n_;
+            ++gen_;
+        }
+        cv_.notify_all();
+    }
+    void wait() {
+        std::unique_lock<std::mutex> l(m_);
+        done_.wait(l, [this] { return pending_ == 0; });
+    }
+    void run(std::function<void(int, int)> fn) {
+        start(std::move(fn));
+        wait();
+    }
+
+  private:
+    void loop(int id) {
+        uint64_t seen = 0;
+        for (;;) {
+            {
+                std::unique_lock<std::mutex> l(m_);
+                cv_.wait(l, [&] { return gen_ != seen; });
+                seen = gen_;
+                if (stop_) return;
+            }
+            fn_(id, n_);                 // fn_ is only replaced by start(), which first waits for pending_ == 0
+            {
+                std::lock_guard<std::mutex> l(m_);
+                if (--pending_ == 0) done_.notify_all();
+            }
+        }
+    }
+    int n_;
+    std::vector<std::thread> threads_;
+    std::mutex m_;
+    std::condition_variable cv_, done_;
+    std::function<void(int, int)> fn_;
+    int pending_ = 0;
+    uint64_t gen_ = 0;
+    bool stop_ = false;
+};
+
+thread_local std::string g_create_err;
+
+}  // namespace
+
+struct agxr_runner {
+    agxr_config cfg;
+    std::vector<std::unique_ptr<Emulator>> emu;
+    std::vector<std::vector<int>> actions;   // per env: index -> emulator action (atari_env.py:51-52)
+    std::vector<int32_t> lives;
+    std::vector<uint8_t> life_termination;
+    bool training = true;                    // atari_env.py:58
+    std::unique_ptr<Pool> pool;
+    AleApi ale;
+    std::string err;
+    // chunked asynchronous step (agxr_step_begin / agxr_step_wait)
+    std::unique_ptr<std::atomic<int>[]> chunk_left;
+    int n_chunks = 0, chunk_envs = 0;
+    bool in_flight = false;               // between agxr_step_begin and agxr_step_wait(-1)
+    std::mutex chunk_m;
+    std::condition_variable chunk_cv;
+};
+
+static int fail(agxr_runner *r, int code, const char *fmt, ...) {
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    if (r) r->err = buf; else g_create_err = buf;
+    return code;
+}
+
+extern "C" {
+
+const char *agxr_last_error(const agxr_runner *r) { return r ? r->err.c_str() : g_create_err.c_str(); }
+
+int agxr_destroy(agxr_runner *r) {
+    if (!r) return AGXR_OK;
+    r->pool.reset();
+    r->emu.clear();
+    if (r->ale.lib) dlclose(r->ale.lib);
+    delete r;
+    return AGXR_OK;
+}
+
+int agxr_create(const agxr_config *cfg, agxr_runner **out) {
+    if (!cfg || !out) return fail(nullptr, AGXR_E_INVALID, "agxr_create: null argument");
+    *out = nullptr;
+    if (cfg->struct_size != (int32_t)sizeof(agxr_config))
+        return fail(nullptr, AGXR_E_INVALID, "agxr_create: struct_size %d != %zu", cfg->struct_size, sizeof(agxr_config));
+    if (cfg->num_envs < 1 || cfg->action_repeat < 1 || !cfg->backend)
+        return fail(nullptr, AGXR_E_INVALID, "agxr_create: num_envs >= 1, action_repeat >= 1 and a backend are required");
+    auto r = std::make_unique<agxr_runner>();
+    r->cfg = *cfg;
+    const std::string be = cfg->backend;
+    if (be == "ale_c") {
+        if (!cfg->ale_lib || !cfg->rom_path) return fail(nullptr, AGXR_E_INVALID, "backend ale_c needs ale_lib and rom_path");
+        const std::string e = r->ale.load(cfg->ale_lib);
+        if (!e.empty()) return fail(nullptr, AGXR_E_BACKEND, "%s", e.c_str());
+    } else if (be != "scripted") {
+        return fail(nullptr, AGXR_E_INVALID, "unknown backend '%s'", cfg->backend);
+    }
+    for (int i = 0; i < cfg->num_envs; ++i) {
+        const int64_t seed = cfg->seed + cfg->env_offset + i;
+        if (be == "scripted")
+            r->emu.emplace_back(new ScriptedEmu((uint64_t)seed, std::max(1, cfg->scripted_actions), std::max(1, cfg->scripted_lives),
+                                                cfg->scripted_p_life, cfg->scripted_p_over));
+        else
+            r->emu.emplace_back(new AleEmu(&r->ale, cfg->rom_path, (int)seed, cfg->max_episode_frames));
+        r->actions.push_back(r->emu.back()->minimal_actions());
+    }
+    r->lives.assign(cfg->num_envs, 0);
+    r->life_termination.assign(cfg->num_envs, 0);
+    int nt = cfg->num_threads > 0 ? cfg->num_threads : (int)std::thread::hardware_concurrency();
+    nt = std::max(1, std::min(nt, cfg->num_envs));
+    r->pool = std::make_unique<Pool>(nt);
+    *out = r.release();
+    return AGXR_OK;
+}
+
+int agxr_num_actions(const agxr_runner *r) { return r ? (int)r->actions[0].size() : AGXR_E_INVALID; }
+
+void agxr_set_training(agxr_runner *r, int training) {
+    if (r) r->training = training != 0;
+}
+
+static void step_env(agxr_runner *r, int i, const int32_t *motor, uint8_t *frames, uint8_t *cmd, double *reward, double *raw,
+                     uint8_t *done) {
+    Emulator &e = *r->emu[i];
+    const int a = r->actions[i][motor[i]];
+    int rew = 0, nvalid = 0;
+    bool d = false;
+    uint8_t *f = frames + (size_t)i * 2 * kFrameBytes;
+    for (int t = 0; t < r->cfg.action_repeat; ++t) {          // atari_env.py:123-131
+        rew += e.act(a);
+        if (t == 2) {
+            e.screen_rgb(f);
+            nvalid = 1;
+        } else if (t == 3) {
+            e.screen_rgb(f + kFrameBytes);
+            nvalid = 2;
+        }
+        d = e.game_over();
+        if (d) break;
+    }
+    if (r->training) {                                           // atari_env.py:135-140
+        const int lv = e.lives();
+        if (lv < r->lives[i] && lv > 0) {
+            r->life_termination[i] = d ? 0 : 1;
+            d = true;
+        }
+        r->lives[i] = lv;
+    }
+    raw[i] = rew;
+    reward[i] = r->cfg.clip_reward ? (double)((rew > 0) - (rew < 0)) : (double)rew;   // np.sign, atari_env.py:144
+    done[i] = d ? 1 : 0;
+    cmd[i] = (uint8_t)nvalid;
+}
+
+int agxr_step_begin(agxr_runner *r, const int32_t *motor, uint8_t *frames, uint8_t *cmd, double *reward, double *raw,
+                    uint8_t *done, int32_t chunk_envs) {
+    if (!r) return AGXR_E_INVALID;
+    if (!motor || !frames || !cmd || !reward || !raw || !done) return fail(r, AGXR_E_INVALID, "agxr_step: null buffer");
+    if (r->in_flight) return fail(r, AGXR_E_STATE, "agxr_step_begin: the previous step has not been waited for");
+    const int N = r->cfg.num_envs;
+    for (int i = 0; i < N; ++i)
+        if (motor[i] < 0 || motor[i] >= (int)r->actions[i].size())
+            return fail(r, AGXR_E_INVALID, "agxr_step: motor action %d of env %d outside [0,%zu)", motor[i], i, r->actions[i].size());
+    if (chunk_envs < 1 || chunk_envs > N) chunk_envs = N;
+    const int nc = (N + chunk_envs - 1) / chunk_envs;
+    if (nc != r->n_chunks) r->chunk_left.reset(new std::atomic<int>[nc]);
+    r->n_chunks = nc;
+    r->chunk_envs = chunk_envs;
+    for (int c = 0; c < nc; ++c) r->chunk_left[c].store(std::min(chunk_envs, N - c * chunk_envs));
+    r->in_flight = true;
+    // static, barrier-free schedule: worker w takes envs lo+w, lo+w+nw, ... of chunk 0, then of chunk 1, ... - env ->
+    // thread stays fixed from step to step (emulator state stays in that core's cache), and chunks complete in
+    // order, so chunk c's screens can be on their way to the GPU while chunk c+1 is still emulating
+    r->pool->start([=](int w, int nw) {
+        for (int c = 0; c < nc; ++c) {
+            const int lo = c * chunk_envs, hi = std::min(N, lo + chunk_envs);
+            int mine = 0;
+            for (int i = lo + w; i < hi; i += nw, ++mine) step_env(r, i, motor, frames, cmd, reward, raw, done);
+            if (mine && r->chunk_left[c].fetch_sub(mine) == mine) {
+                std::lock_guard<std::mutex> l(r->chunk_m);
+                r->chunk_cv.notify_all();
+            }
+        }
+    });
+    return AGXR_OK;
+}
+
+int agxr_step_wait(agxr_runner *r, int32_t chunk) {
+    if (!r) return AGXR_E_INVALID;
+    if (chunk < 0) {
+        r->pool->wait();
+        r->in_flight = false;
+        return AGXR_OK;
+    }
+    if (!r->in_flight || chunk >= r->n_chunks) return fail(r, AGXR_E_INVALID, "agxr_step_wait: chunk %d of %d", chunk, r->n_chunks);
+    std::unique_lock<std::mutex> l(r->chunk_m);
+    r->chunk_cv.wait(l, [&] { return r->chunk_left[chunk].load() == 0; });
+    return AGXR_OK;
+}
+
+int agxr_step(agxr_runner *r, const int32_t *motor, uint8_t *frames, uint8_t *cmd, double *reward, double *raw, uint8_t *done) {
+    const int rc = agxr_step_begin(r, motor, frames, cmd, reward, raw, done, 0);
+    return rc ? rc : agxr_step_wait(r, -1);
+}
+
+int agxr_reset(agxr_runner *r, const int32_t *idx, int32_t k, const int32_t *noops, uint8_t *frames, int64_t env_stride,
+               uint8_t *cmd) {
+    if (!r) return AGXR_E_INVALID;
+    if (!idx || !noops || !frames || !cmd || k < 0) return fail(r, AGXR_E_INVALID, "agxr_reset: bad argument");
+    if (r->in_flight) return fail(r, AGXR_E_STATE, "agxr_reset: a step is in flight (agxr_step_wait(-1) first)");
+    const int N = r->cfg.num_envs;
+    for (int j = 0; j < k; ++j)
+        if (idx[j] < 0 || idx[j] >= N) return fail(r, AGXR_E_INVALID, "agxr_reset: env index %d out of range", idx[j]);
+    std::fill(cmd, cmd + N, kCmdSkip);
+    r->pool->run([&](int w, int nw) {
+        const int lo = (int)((int64_t)k * w / nw), hi = (int)((int64_t)k * (w + 1) / nw);
+        for (int j = lo; j < hi; ++j) {
+            const int i = idx[j];
+            Emulator &e = *r->emu[i];
+            uint8_t clear = 0;
+            if (r->life_termination[i]) {                               // atari_env.py:86-88
+                r->life_termination[i] = 0;
+                e.act(0);
+            } else {                                                     // atari_env.py:90-99
+                clear = kCmdClear;
+                e.reset_game();
+                for (int t = 0; t < noops[j]; ++t) {
+                    e.act(0);
+                    if (e.game_over()) e.reset_game();
+                }
+            }
+            if (r->actions[i].size() >= 3) {                            // fire reset, atari_env.py:102-108
+                e.act(1);
+                if (e.game_over()) {
+                    e.reset_game();
+                    e.act(2);
+                }
+                if (e.game_over()) e.reset_game();
+            }
+            e.screen_rgb(frames + (size_t)i * env_stride);
+            r->lives[i] = e.lives();
+            cmd[i] = (uint8_t)(1 | clear);
+        }
+    });
+    return AGXR_OK;
+}
+
+int agxr_get_state(const agxr_runner *r, int32_t *lives, uint8_t *life_termination) {
+    if (!r) return AGXR_E_INVALID;
+    if (lives) std::copy(r->lives.begin(), r->lives.end(), lives);
+    if (life_termination) std::copy(r->life_termination.begin(), r->life_termination.end(), life_termination);
+    return AGXR_OK;
+}
+
+int agxr_render(agxr_runner *r, int32_t i, uint8_t *out) {
+    if (!r || !out || i < 0 || i >= r->cfg.num_envs) return AGXR_E_INVALID;
+    r->emu[i]->screen_rgb(out);
+    return AGXR_OK;
+}
+
+}  // extern "C"

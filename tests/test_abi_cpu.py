@@ -58,3 +58,24 @@ def test_create_fails_loudly_without_gpu_or_bad_config():
         from active_gym import ObsPipeline
         with pytest.raises(RuntimeError, match="no CPU implementation"):
             ObsPipeline(4, "fixed", fov_size=(30, 30))
+
+
+def test_runner_library_exports_header_surface():
+    """include/agx_runner.h (native host runner) <-> libagx_runner.so <-> ctypes binding."""
+    spec = importlib.util.spec_from_file_location("agx_build", os.path.join(REPO, "active-gym_amd", "build.py"))
+    m = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(m)
+    path = m.build_runner()
+    src = open(os.path.join(REPO, "include", "agx_runner.h")).read()
+    names = sorted(set(re.findall(r"^AGXR_API[^;(]*?\b(agxr_\w+)\s*\(", src, flags=re.M)))
+    assert len(names) == 11
+    handle = ctypes.CDLL(path)
+    for name in names:
+        assert hasattr(handle, name), name
+    from active_gym import native_runner as nr
+    assert sorted(nr.SIGNATURES) == names
+    cfg = nr.AgxrConfig()
+    cfg.struct_size = 4
+    h = ctypes.c_void_p()
+    assert nr.lib().agxr_create(ctypes.byref(cfg), ctypes.byref(h)) != 0 and not h.value
+    assert b"struct_size" in nr.lib().agxr_last_error(None)

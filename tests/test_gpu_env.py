@@ -34,7 +34,11 @@ class _Noops:
 
 
 def _oracle_env(i, args, noop_iter, kind, antialias=True):
-    ale = ScriptedALE(seed=300 + i, n_actions=4, p_life=0.05, p_over=0.01)
+    if getattr(args, "frame_source", None) == "native":       # the C++ runner's scripted emulator, mirrored in Python
+        from lcg_ale import LcgALE
+        ale = LcgALE(args.seed + i, args.scripted_actions, args.scripted_lives, args.scripted_p_life, args.scripted_p_over)
+    else:
+        ale = ScriptedALE(seed=300 + i, n_actions=4, p_life=0.05, p_over=0.01)
     env = O.AtariEnvOracle(ale, ale.getMinimalActionSet(), obs_size=(84, 84), frame_stack=args.frame_stack,
                            action_repeat=args.action_repeat, clip_reward=args.clip_reward,
                            noop_fn=lambda: int(next(noop_iter)), prefer_rgb=True)
@@ -59,6 +63,11 @@ def _oracle_env(i, args, noop_iter, kind, antialias=True):
     ("peripheral", dict(resize_to_full=False, peripheral_res=(20, 20))),
     ("flexible", dict(resize_to_full=True)),
     ("base", dict()),
+    # the same chain fed by the native C++ host runner (libagx_runner.so) instead of the Python one
+    ("fixed", dict(resize_to_full=True, frame_source="native", scripted_actions=4, scripted_lives=3, scripted_p_life=50,
+                   scripted_p_over=10, h2d_chunk_envs=2)),        # chunked: H2D of chunk c overlaps emulation of c+1
+    ("flexible", dict(resize_to_full=False, mask_out=True, frame_source="native", scripted_actions=4, scripted_lives=2,
+                      scripted_p_life=50, scripted_p_over=10, clip_reward=True)),
 ])
 def test_vec_env_matches_oracle_with_autoreset(kind, extra):
     from active_gym import AtariVecEnv

@@ -1,0 +1,115 @@
+"""CPU: the C++ host runner (libagx_runner.so) against the Python runner (itself pinned to the reference's
+control flow by tests/test_runner_cpu.py), both over the same scripted emulator: screens, command bytes,
+rewards, dones, lives and life-termination flags must agree bit for bit, with resets interleaved."""
+import importlib.util
+import os
+
+import numpy as np
+import pytest
+
+from lcg_ale import LcgALE
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _build():
+    spec = importlib.util.spec_from_file_location("agx_build", os.path.join(REPO, "active-gym_amd", "build.py"))
+    m = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(m)
+    return m.build_runner()
+
+
+class _Args:
+    def __init__(self, **kw):
+        self.__dict__.update(kw)
+
+
+@pytest.mark.parametrize("ar,clip,training,n_act", [(4, False, True, 4), (4, True, False, 6), (3, False, True, 2), (6, False, True, 4)])
+def test_native_runner_equals_python_runner(ar, clip, training, n_act):
+    _build()
+    from active_gym.native_runner import NativeHostRunner
+    from active_gym.runner import AtariHostRunner
+    N = 5
+    common = dict(game="g", seed=77, action_repeat=ar, clip_reward=clip, max_episode_length=108e3,
+                  scripted_actions=n_act, scripted_lives=3, scripted_p_life=60, scripted_p_over=15)
+    py = AtariHostRunner(_Args(frame_source=lambda a, i: LcgALE(77 + i, n_act, 3, 60, 15), **common), N, workers=2,
+                         noop_fn=lambda: 3, env_offset=0)
+    nv = NativeHostRunner(_Args(**common), N, workers=3, noop_fn=lambda: 3, env_offset=0, backend="scripted")
+    if not training:
+        py.eval()
+        nv.eval()
+    assert nv.num_actions == py.num_actions == n_act
+    rng = np.random.default_rng(1)
+    ca, cb = py.reset(), nv.reset()
+    assert np.array_equal(ca, cb) and np.array_equal(py.frames[:, 0], nv.frames[:, 0])
+    assert np.array_equal(py.lives, nv.lives)
+    n_done = 0
+    for step in range(120):
+        m = rng.integers(0, n_act, N)
+        a, b = py.step(m), nv.step(m)
+        for x, y in zip(a, b):
+            assert np.array_equal(x, y), step
+        nvalid = a[2]
+        for i in range(N):                              # only the sampled slots are defined
+            for s in range(int(nvalid[i])):
+                assert np.array_equal(py.frames[i, s], nv.frames[i, s]), (step, i, s)
+        assert np.array_equal(py.lives, nv.lives) and np.array_equal(py.life_termination, nv.life_termination)
+        d = np.nonzero(a[1])[0]
+        if len(d):
+            n_done += len(d)
+            ra = np.zeros((N, 1, 210, 160, 3), np.uint8)
+            rb = np.zeros((N, 1, 210, 160, 3), np.uint8)
+            assert np.array_equal(py.reset(d, out=ra), nv.reset(d, out=rb))
+            assert np.array_equal(ra, rb)
+    assert n_done >= 5
+    py.close()
+    nv.close()
+
+
+def test_native_runner_errors_and_sharding_identity():
+    _build()
+    from active_gym.native_runner import NativeHostRunner
+    common = dict(game="g", seed=5, action_repeat=4, clip_reward=False, max_episode_length=108e3)
+    r = NativeHostRunner(_Args(**common), 4, backend="scripted")
+    with pytest.raises(RuntimeError, match="motor action"):
+        r.step([0, 1, 9, 0])
+    full = NativeHostRunner(_Args(**common), 6, noop_fn=lambda: 1, backend="scripted")
+    part = NativeHostRunner(_Args(**common), 3, noop_fn=lambda: 1, env_offset=3, backend="scripted")
+    full.reset(); part.reset()
+    assert np.array_equal(full.frames[3:, 0], part.frames[:, 0])          # env identity = seed + global index
+    with pytest.raises(RuntimeError, match="backend"):
+        NativeHostRunner(_Args(**common), 2, backend="nope")
+
+
+def test_chunked_async_step_equals_blocking_step():
+    _build()
+    from active_gym.native_runner import NativeHostRunner
+    common = dict(game="g", seed=11, action_repeat=4, clip_reward=False, max_episode_length=108e3, scripted_p_life=40,
+                  scripted_p_over=10)
+    N = 37
+    a = NativeHostRunner(_Args(**common), N, workers=4, noop_fn=lambda: 2, backend="scripted")
+    b = NativeHostRunner(_Args(**common), N, workers=3, noop_fn=lambda: 2, backend="scripted")
+    a.reset(); b.reset()
+    rng = np.random.default_rng(0)
+    for step in range(40):
+        m = rng.integers(0, 4, N)
+        ra = a.step(m)
+        nc = b.step_begin(m, 8)
+        assert nc == 5
+        with pytest.raises(RuntimeError, match="in flight|not been waited"):
+            b.reset([0]) if step % 2 else b.step_begin(m, 8)
+        for c in range(nc):
+            b.step_wait(c)
+            lo, hi = c * 8, min(N, c * 8 + 8)
+            for i in range(lo, hi):                                  # chunk c is complete once its wait returns
+                for s_ in range(int(b._cmd[i])):
+                    assert np.array_equal(a.frames[i, s_], b.frames[i, s_])
+        rb = b.step_finish()
+        for x, y in zip(ra, rb):
+            assert np.array_equal(x, y)
+        d = np.nonzero(ra[1])[0]
+        if len(d):
+            oa = np.zeros((N, 1, 210, 160, 3), np.uint8); ob = np.zeros_like(oa)
+            assert np.array_equal(a.reset(d, out=oa), b.reset(d, out=ob)) and np.array_equal(oa, ob)
+    with pytest.raises(RuntimeError, match="chunk"):
+        b.step_wait(99)
