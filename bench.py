@@ -148,8 +148,8 @@ def cpu_baseline(budget_s, seed):
 
 def barrier(dist, local_rank):
     """All ranks rendezvous (no-op for a single process)."""
-    if dist is not None and dist.is_initialized() and dist.get_world_size() > 1:
-        if local_rank is None:
+    if dist is not None and dist.is_initialized():
+        if local_rank is None or dist.get_backend() != "nccl":
             dist.barrier()
         else:
             dist.barrier(device_ids=[local_rank])
@@ -157,10 +157,10 @@ def barrier(dist, local_rank):
 
 def max_over_ranks(value, dist, device):
     """MAX of a per-rank scalar (the timed region's duration) over all ranks."""
-    if dist is None or not dist.is_initialized() or dist.get_world_size() == 1:
+    if dist is None or not dist.is_initialized():
         return float(value)
     import torch
-    t = torch.tensor([value], dtype=torch.float64, device=device)
+    t = torch.tensor([value], dtype=torch.float64, device=device if dist.get_backend() == "nccl" else "cpu")
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
     return float(t.item())
 
@@ -184,12 +184,21 @@ def main():
     import torch
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a ROCm GPU (the observation path has no CPU implementation)")
+    # Rehearsal hooks for a one-GPU box (never set by the driver): AGX_BENCH_SHARE_GPU=1 lets several ranks share
+    # cuda:0, AGX_BENCH_BACKEND=gloo swaps the control-plane backend (RCCL refuses two ranks on one device),
+    # AGX_BENCH_FORCE_DIST=1 initialises the process group even for a single rank (exercises RCCL itself).
+    if os.environ.get("AGX_BENCH_SHARE_GPU") == "1":
+        local_rank %= torch.cuda.device_count()
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     dist = None
-    if world > 1:
+    if world > 1 or os.environ.get("AGX_BENCH_FORCE_DIST") == "1":
         import torch.distributed as dist
-        dist.init_process_group("nccl", device_id=dev)
+        backend = os.environ.get("AGX_BENCH_BACKEND", "nccl")
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)          # RCCL; used for barrier + MAX of the timing only
+        else:
+            dist.init_process_group(backend)
 
     n = args.envs
     pipe = make_pipeline(args.kind, n, dev)
