@@ -146,6 +146,27 @@ def cpu_baseline(budget_s, seed):
             "sample": f"{n} envs x {reps} steps of the same config through oracle/oracle.py (NumPy, single thread), {el:.1f} s"}
 
 
+def pmc_traffic(kernel, n_envs, kind):
+    """HBM bytes per launch of `kernel` from the committed PMC profile (profiles/r*_traffic.json: FETCH_SIZE and
+    WRITE_SIZE collected in separate rocprofv3 --pmc passes of this same command by tools/traffic.sh, FETCH_SIZE
+    x2 as MI355X_MICROARCH.md prescribes for gfx950 - the factor re-measured on 12 B/lane and 16 B/lane reads of a
+    known byte count).  Counters cannot be read from inside the process, so this is the profile's number, quoted
+    only for the configuration it was collected on; otherwise None."""
+    import glob
+    if n_envs != 1024 or kind != "fixed":
+        return None
+    files = sorted(glob.glob(os.path.join(REPO, "profiles", "r*_traffic.json")))
+    if not files:
+        return None
+    try:
+        prof = json.load(open(files[-1]))
+        e = prof["kernels"][kernel]
+        return {"traffic": float(e["traffic"]),
+                "note": f"{os.path.relpath(files[-1], REPO)}: FETCH_SIZE x {e['fetch_factor_used']:.3f} + WRITE_SIZE, separate --pmc passes"}
+    except (KeyError, ValueError, OSError):
+        return None
+
+
 def barrier(dist, local_rank):
     """All ranks rendezvous (no-op for a single process)."""
     if dist is not None and dist.is_initialized():
@@ -281,6 +302,11 @@ def main():
                     "unit": "GB/s", "frac": kernels[dom]["frac"], "traffic": None,
                     "avg_launch_us": kernels[dom]["avg_us"], "algorithmic_bytes_per_launch": kernels[dom]["algorithmic_bytes"],
                     "launches_timed": len(ev), "timing": f"HIP events on the launch stream around every {M}th step of the timed region"}
+            tr = pmc_traffic(dom, n, args.kind)
+            if tr is not None:
+                roof["traffic"] = tr["traffic"]
+                roof["traffic_unit"] = "bytes per launch"
+                roof["traffic_source"] = tr["note"]
         out = {
             "metric": "env steps/sec at N=1024 AtariFixedFovealEnv; 1/2/4/8-GPU scaling",
             "value": total_envs * K / elapsed, "unit": "env steps/s", "n_gpus": world, "steps": K, "warmup": args.warmup,

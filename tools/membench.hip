@@ -53,6 +53,15 @@ __global__ __launch_bounds__(256) void k_lin(const uint4* src, uint32_t* out, si
   for (int it=0; it<6; ++it) acc ^= w[it].x ^ w[it].y ^ w[it].z ^ w[it].w;
   if (acc == 0x12345678u) out[0] = acc;
 }
+// (c3) whole frames linearly, 12 B per lane (K1's load width, no partial-line waste): FETCH_SIZE calibration
+__global__ __launch_bounds__(256) void k_lin3(const uint8_t* src, uint32_t* out, size_t n12) {
+  size_t i = (size_t)blockIdx.x * 256 * 8 + threadIdx.x; uint32_t acc=0; U3 w[8];
+#pragma unroll
+  for (int it=0; it<8; ++it) { size_t j = i + 256*it; if (j >= n12) j = n12-1; w[it] = *reinterpret_cast<const U3*>(src + j*12); }
+#pragma unroll
+  for (int it=0; it<8; ++it) acc ^= w[it].x ^ w[it].y ^ w[it].z;
+  if (acc == 0x12345678u) out[0] = acc;
+}
 // (d) like (a) but one WG per env walking its 7 bands with the loads of band b+1 issued before band b is reduced
 __global__ __launch_bounds__(256) void k_x3_pipe(const uint8_t* frames, uint32_t* out) {
   const int n = blockIdx.y, tid = threadIdx.x;
@@ -98,10 +107,28 @@ __global__ __launch_bounds__(256) void k_st252(float4* out, float v, int nt) {
     float4 o = make_float4(v, v+q, v, v);
     if (nt) { typedef float f4 __attribute__((ext_vector_type(4))); f4 w = {o.x,o.y,o.z,o.w}; __builtin_nontemporal_store(w, (f4*)&out[base+q]); } else out[base+q] = o; }
 }
-int main() {
+int main(int argc, char** argv) {
   const int N=1024, POOL=8; const size_t bytes=(size_t)N*2*FRAMEB;
   std::vector<uint8_t*> bufs(POOL); uint32_t* out; CK(hipMalloc(&out, 4096));
   for (auto& b: bufs) { CK(hipMalloc(&b, bytes)); CK(hipMemset(b, 0x5a, bytes)); }
+  if (argc > 1 && argv[1][0] == 'c') {
+    // calibration mode for `rocprofv3 --pmc FETCH_SIZE|WRITE_SIZE -- tools/membench cal`: a few launches of each
+    // known-byte-count kernel over a 1.65 GB pool (past the 256 MiB Infinity Cache), nothing else
+    float4* ob; size_t ob_bytes=(size_t)N*4*1764*16; CK(hipMalloc(&ob, ob_bytes));
+    const size_t n16=bytes/16, n12=bytes/12;
+    for (int r=0; r<POOL; ++r) {
+      uint8_t* f = bufs[r];
+      hipLaunchKernelGGL(k_lin, dim3((n16+1535)/1536), dim3(256), 0, 0, (const uint4*)f, out, n16);
+      hipLaunchKernelGGL(k_lin3, dim3((n12+2047)/2048), dim3(256), 0, 0, f, out, n12);
+      hipLaunchKernelGGL(k_x3, dim3(7,N), dim3(256), 0, 0, f, out);
+      hipLaunchKernelGGL(k_st, dim3(4,N), dim3(256), 0, 0, ob, (float)r, 0);
+      hipLaunchKernelGGL(k_st, dim3(4,N), dim3(256), 0, 0, ob, (float)r, 1);
+    }
+    CK(hipDeviceSynchronize());
+    printf("cal: k_lin reads %zu B, k_lin3 reads %zu B, k_x3 reads %zu B (algorithmic), k_st writes %zu B per launch\n",
+           bytes, n12*12, (size_t)N*2*168*ROWB, ob_bytes);
+    return 0;
+  }
   hipEvent_t e0,e1; hipEventCreate(&e0); hipEventCreate(&e1);
   const double alg = (double)N*2*168*ROWB;      // touched rows only
   for (int kind=0; kind<4; ++kind) {
