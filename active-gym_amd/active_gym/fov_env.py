@@ -126,8 +126,13 @@ class FixedFovealEnv(_SingleEnv):
         o = self._obs(obs, info)
         rec = self._rec()
         if rec:
-            rec.on_reset(o, info, fovea=self)
+            rec.on_reset(self._full_state(), info, fovea=self)
         return o, info
+
+    def _full_state(self):
+        """The wrapped env's full-frame state (what the reference's RecordWrapper sits on and records,
+        fov_env.py:59,74): float64 [fs, H, W] from the device ring.  Recording only."""
+        return self._core().pipe.observe_full()[0].cpu().numpy().astype(np.float64)
 
     def _sync(self, info):
         self.fov_loc = info["fov_loc"]
@@ -152,7 +157,7 @@ class FixedFovealEnv(_SingleEnv):
         ret = r[0].item()
         rec = self._rec()
         if rec:
-            rec.on_step(o, action["motor_action"], info["reward"], bool(d[0]), False, info, ret, fovea=self)
+            rec.on_step(self._full_state(), action["motor_action"], info["reward"], bool(d[0]), False, info, ret, fovea=self)
         return o, ret, bool(d[0]), False, info
 
 

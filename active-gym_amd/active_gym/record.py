@@ -81,9 +81,11 @@ class Recorder:
             b["return_reward"].append(return_reward)
 
     def on_reset(self, state, info, fovea=None):
+        """`state` is the FULL-frame state of the wrapped base env (the reference's RecordWrapper sits below
+        the fovea wrapper, fov_env.py:43-56), float64 like the reference's."""
         rgb = self.w.env.render()
         self._new_buffer()
-        self._save(state, done=False, info=info, rgb=rgb)
+        self._save(np.asarray(state, dtype=np.float64), done=False, info=info, rgb=rgb)
         if fovea is not None:
             b = self.w.record_buffer
             b["fov_size"] = fovea.fov_size
@@ -95,7 +97,8 @@ class Recorder:
 
     def on_step(self, state, action, cum_reward, done, truncated, info, return_reward, fovea=None):
         rgb = self.w.env.render()
-        self._save(state, action, cum_reward, done, truncated, info, rgb=rgb, return_reward=return_reward)
+        self._save(np.asarray(state, dtype=np.float64), action, cum_reward, done, truncated, info, rgb=rgb,
+                   return_reward=return_reward)
         if fovea is not None and not done:
             b = self.w.record_buffer
             b["fov_loc"].append(info["fov_loc"])

@@ -378,6 +378,8 @@ int agx_create(const agx_config *cfg, agx_ctx **out) {
         ctx->ingest_t = (forced_t == 128 || forced_t == 256) ? forced_t : 256;   // 8 WGs/CU whatever T: 256 fills the wave slots
         if (ow4 > 128) ctx->ingest_t = 256;
         ctx->band_rows = std::max(1, std::min(2 * (ctx->ingest_t / 40), ctx->ingest_t / ow4));
+        static const int forced_br = [] { const char *e = getenv("AGX_INGEST_BAND_ROWS"); return e ? atoi(e) : 0; }();
+        if (forced_br >= 1 && forced_br <= ctx->band_rows) ctx->band_rows = forced_br;     // tuning: bands per env
     }
     if (has_fovea(c)) {
         // _init_fov_loc: np.rint(fov_init_loc).astype(np.int32)  (not clipped)   fov_env.py:149-150

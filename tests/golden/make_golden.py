@@ -115,6 +115,23 @@ def _install_standins():
         return img.copy()
 
     cv2.resize = resize
+
+    # VideoWriter: records what the reference writes (no encoding) - used by the record goldens only
+    class VideoWriter:
+        log = []
+
+        def __init__(self, path, fourcc, fps, size):
+            self.entry = {"path": path, "fourcc": fourcc, "fps": fps, "size": tuple(size), "frames": []}
+            VideoWriter.log.append(self.entry)
+
+        def write(self, frame):
+            self.entry["frames"].append(np.asarray(frame).copy())
+
+        def release(self):
+            self.entry["released"] = True
+
+    cv2.VideoWriter = VideoWriter
+    cv2.VideoWriter_fourcc = lambda *c: "".join(c)
     sys.modules["cv2"] = cv2
 
     # atari_py
@@ -369,13 +386,127 @@ def make_atari(atari_env):
     ]
 
 
+# ------------------------------------------------------------------ record-buffer goldens
+def _record_case(fov_env, gym, kind, name, seed, tmpdir):
+    """RecordWrapper(record=True) under each fovea wrapper (fov_env.py:34-37,51-55,64-102,152-154,161-163,
+    207,218-220,253-256,265-267,334-335,352-354,370-373): two episodes + the start of a third, then
+    save_record_to_file() of the finished one.  Emits the driving sequence and both buffers."""
+    import cv2
+    obs, fov, fs = (12, 12), (4, 4), 2
+    rng = np.random.default_rng(seed)
+    T = 16
+    states_u8 = rng.integers(0, 256, size=(T + 4, fs) + obs, dtype=np.uint8)
+    rgbs = rng.integers(0, 256, size=(T + 4, 6, 5, 3), dtype=np.uint8)
+    base_rewards = rng.integers(-2, 5, size=T + 4).astype(np.float64)
+    done_at = {4, 11}                      # global step indices that end an episode
+    _STATE["antialias"] = True
+    clock = {"g": 0}                       # counts every reset/step of the base env -> index into states/rgbs
+
+    class FakeBase(gym.Env):
+        def __init__(self):
+            self.obs_size, self.frame_stack = obs, fs
+            self.action_space = gym.spaces.Discrete(4)
+
+        def reset(self, seed=None, options=None):
+            clock["g"] += 1
+            return _unit(states_u8[clock["g"]]), {"raw_reward": 0}
+
+        def step(self, action):
+            clock["g"] += 1
+            g = clock["g"]
+            return _unit(states_u8[g]), float(np.sign(base_rewards[g])), (g in done_at), False, {"raw_reward": float(base_rewards[g])}
+
+        def render(self):
+            return rgbs[clock["g"]]
+
+    args = _Args(fov_size=fov, fov_init_loc=(1, 2), sensory_action_mode="absolute", sensory_action_space=(-3.0, 3.0),
+                 resize_to_full=True, mask_out=False, peripheral_res=(5, 5), record=True)
+    base = fov_env.RecordWrapper(FakeBase(), args)
+    env = base if kind == "base" else {"fixed": fov_env.FixedFovealEnv, "flex": fov_env.FlexibleFovealEnv,
+                                       "per": fov_env.FixedFovealPeripheralEnv}[kind](base, args)
+    clock["g"] = -1
+    drive = []                              # (is_reset, motor, sens0, sens1, type)
+    env.reset()
+    drive.append((1, 0, 0, 0, 0))
+    while clock["g"] < T - 1:
+        motor = int(rng.integers(0, 4))
+        sens = rng.integers(-1, 10, size=2)
+        typ = int(rng.integers(0, 2)) if kind == "flex" else 0
+        if typ == 1:
+            sens = rng.integers(2, 9, size=2)
+        if kind == "base":
+            _, _, d, _, _ = env.step(motor)
+        else:
+            # the flexible env stores a FOV_RES action unrounded (fov_env.py:322) and slices with it: integers there
+            act = {"motor_action": motor, "sensory_action": sens.astype(np.int64 if kind == "flex" else np.float64)}
+            if kind == "flex":
+                act["sensory_action_type"] = np.array((typ,))
+            _, _, d, _, _ = env.step(act)
+        drive.append((0, motor, int(sens[0]), int(sens[1]), typ))
+        if d:
+            env.reset()
+            drive.append((1, 0, 0, 0, 0))
+    rec = {"kind": kind, "obs_size": np.array(obs), "fov_size": np.array(fov), "frame_stack": fs, "init_loc": np.array((1, 2)),
+           "peripheral_res": np.array((5, 5)), "states_u8": states_u8, "rgbs": rgbs, "base_rewards": base_rewards,
+           "done_at": np.array(sorted(done_at)), "drive": np.array(drive, dtype=np.int64)}
+
+    def dump(tag, buf):
+        rec[f"{tag}_keys"] = np.array(sorted(buf.keys()))
+        for k in ("rgb", "state", "action", "reward", "done", "truncated", "info", "return_reward", "fov_loc", "fov_res"):
+            if k in buf:
+                rec[f"{tag}_len_{k}"] = len(buf[k])
+        rec[f"{tag}_rgb"] = np.stack(buf["rgb"])
+        rec[f"{tag}_state"] = np.stack(buf["state"])
+        assert rec[f"{tag}_state"].dtype == np.float64
+        for k in ("action", "reward", "done", "truncated", "return_reward"):
+            rec[f"{tag}_{k}"] = np.array(buf[k])
+        for k in ("fov_loc", "fov_res"):
+            if k in buf:
+                rec[f"{tag}_{k}"] = np.array(buf[k], dtype=np.int64)
+        for k in ("fov_size", "peripheral_res"):
+            if k in buf:
+                rec[f"{tag}_{k}"] = np.array(buf[k])
+        infos = buf["info"]
+        for k in ("raw_reward", "reward", "ep_len"):
+            rec[f"{tag}_info_{k}"] = np.array([i[k] for i in infos], dtype=np.float64)
+        rec[f"{tag}_info_keys"] = np.array(sorted(infos[-1].keys())) if infos else np.array([])
+        if infos and "fov_loc" in infos[-1]:
+            rec[f"{tag}_info_fov_loc"] = np.array([i["fov_loc"] for i in infos], dtype=np.int64)
+
+    dump("prev", base.prev_record_buffer)
+    dump("cur", base.record_buffer)
+    # save_record_to_file of the finished episode
+    cv2.VideoWriter.log.clear()
+    pt = os.path.join(tmpdir, f"{name}.pt")
+    n_rgb = len(base.prev_record_buffer["rgb"])
+    base.save_record_to_file(pt)
+    vw = cv2.VideoWriter.log[-1]
+    saved = torch.load(pt, weights_only=False)            # written two lines above by this script
+    rec["save_video_suffix"] = os.path.basename(vw["path"])[len(name):]
+    rec["save_fourcc"], rec["save_fps"], rec["save_size"] = vw["fourcc"], vw["fps"], np.array(vw["size"])
+    rec["save_frames"] = len(vw["frames"])
+    assert len(vw["frames"]) == n_rgb and vw.get("released")
+    rec["saved_keys"] = np.array(sorted(saved.keys()))
+    rec["saved_rgb_is_path"] = isinstance(saved["rgb"], str) and saved["rgb"] == vw["path"]
+    rec["saved_state"] = np.array(saved["state"])
+    path = os.path.join(HERE, f"record_{name}.npz")
+    np.savez_compressed(path, **rec)
+    return path
+
+
+def make_record(fov_env, gym):
+    import tempfile
+    with tempfile.TemporaryDirectory() as tmp:
+        return [_record_case(fov_env, gym, k, k, 900 + i, tmp) for i, k in enumerate(("base", "fixed", "flex", "per"))]
+
+
 def main():
     if not os.path.isdir(REF):
         raise SystemExit(f"reference checkout not found at {REF}; goldens are generated in the build container only")
     _install_standins()
     fov_env, atari_env = _load_reference()
     gym = sys.modules["gymnasium"]
-    paths = make_fovea(fov_env, gym) + make_atari(atari_env)
+    paths = make_fovea(fov_env, gym) + make_atari(atari_env) + make_record(fov_env, gym)
     total = 0
     for p in paths:
         sz = os.path.getsize(p)

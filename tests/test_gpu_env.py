@@ -241,6 +241,11 @@ def test_recording_buffer_keys(tmp_path):
     buf = rw.prev_record_buffer
     assert set(buf) >= {"rgb", "state", "action", "reward", "done", "truncated", "info", "return_reward", "fov_size", "fov_loc"}
     assert buf["rgb"][0].shape == (256, 256, 3) and len(buf["action"]) == n
+    # the reference's RecordWrapper sits under the fovea wrapper: it records the FULL state, float64 (fov_env.py:59,74)
+    assert buf["state"][0].shape == (4, 84, 84) and buf["state"][0].dtype == np.float64
+    assert len(buf["state"]) == len(buf["rgb"]) == len(buf["fov_loc"]) == n          # n - 1 non-terminal steps + reset
+    assert len(buf["done"]) == len(buf["info"]) == n and buf["done"][-1] is True and not any(buf["done"][:-1])
+    assert np.array_equal(buf["fov_loc"][-1], (5, 7)) and buf["info"][-1]["ep_len"] == n
     path = str(tmp_path / "rec.pt")
     rw.save_record_to_file(path)
     saved = torch.load(path, weights_only=False)
