@@ -47,9 +47,13 @@ class RecordWrapper(_SingleEnv):
     def _core(self):
         return self.unwrapped._core
 
+    def _base_keys(self):
+        """info keys the base env contributes besides raw_reward (DMC: internal_state, discount)."""
+        return tuple(k for k in getattr(self.unwrapped, "_KEYS", ()) if k != "raw_reward")
+
     def reset(self, seed=None, options=None):
         obs, infos = self._core().reset()
-        info = self._scalar_info(infos, ("raw_reward", "reward", "ep_len"))
+        info = self._scalar_info(infos, ("raw_reward", "reward", "ep_len") + self._base_keys())
         if self._rec:
             self._rec.on_reset(obs[0], info)
         return obs[0], info
@@ -57,7 +61,7 @@ class RecordWrapper(_SingleEnv):
     def step(self, action):
         core = self._core()
         obs, r, d, t, infos = core.step(np.asarray([action]) if core.kind == "base" else action)
-        info = self._scalar_info(infos, ("raw_reward", "reward", "ep_len"))
+        info = self._scalar_info(infos, ("raw_reward", "reward", "ep_len") + self._base_keys())
         ret = r[0].item()
         if self._rec:
             self._rec.on_step(obs[0], action, info["reward"], bool(d[0]), False, info, ret)
@@ -79,9 +83,9 @@ class FixedFovealEnv(_SingleEnv):
         self.env = env
         self.args = args
         base = self.unwrapped
-        if not isinstance(base, AtariEnv):
-            raise TypeError("the fovea wrappers drive the libagx device core and need an active_gym AtariEnv "
-                            "underneath (other simulators are not wired to the HIP pipeline yet)")
+        if not hasattr(base, "_rekind"):
+            raise TypeError("the fovea wrappers drive the libagx device core and need an active_gym AtariEnv or DMCEnv "
+                            "underneath (other simulators are not wired to the HIP pipeline)")
         self.fov_size = tuple(args.fov_size)
         self.fov_init_loc = tuple(args.fov_init_loc)
         assert (np.array(self.fov_size) < np.array(base.obs_size)).all()         # fov_env.py:112
@@ -108,6 +112,9 @@ class FixedFovealEnv(_SingleEnv):
     def _core(self):
         return self.unwrapped._core
 
+    def _base_keys(self):
+        return tuple(k for k in getattr(self.unwrapped, "_KEYS", ()) if k != "raw_reward")
+
     def _obs(self, obs, info):
         return obs[0]
 
@@ -121,7 +128,7 @@ class FixedFovealEnv(_SingleEnv):
 
     def reset(self):                                               # takes no arguments, fov_env.py:156
         obs, infos = self._core().reset()
-        info = self._scalar_info(infos, self._INFO_KEYS)
+        info = self._scalar_info(infos, self._INFO_KEYS + self._base_keys())
         self._sync(info)
         o = self._obs(obs, info)
         rec = self._rec()
@@ -138,7 +145,11 @@ class FixedFovealEnv(_SingleEnv):
         self.fov_loc = info["fov_loc"]
 
     def _action(self, action):
-        a = {"motor_action": np.asarray([action["motor_action"]]).reshape(1),
+        m = action["motor_action"]
+        if isinstance(m, torch.Tensor):
+            m = m.detach().cpu().numpy()
+        discrete = hasattr(self._core().single_motor_space, "n")          # Atari: one index; DMC: a Box vector
+        a = {"motor_action": np.asarray(m).reshape(1) if discrete else np.asarray(m).reshape(1, -1),
              "sensory_action": self._one(action["sensory_action"], 2)}
         return a
 
@@ -151,7 +162,7 @@ class FixedFovealEnv(_SingleEnv):
 
     def step(self, action):
         obs, r, d, t, infos = self._core().step(self._action(action))
-        info = self._scalar_info(infos, self._INFO_KEYS)
+        info = self._scalar_info(infos, self._INFO_KEYS + self._base_keys())
         self._sync(info)
         o = self._obs(obs, info)
         ret = r[0].item()

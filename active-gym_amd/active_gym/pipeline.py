@@ -124,7 +124,7 @@ class ObsPipeline:
         return C.c_void_p(t.data_ptr())
 
     def algorithmic_bytes(self, kernel: str) -> int:
-        k = {"ingest": nat.K_INGEST, "fovea": nat.K_FOVEA, "full": nat.K_FULL}[kernel]
+        k = {"ingest": nat.K_INGEST, "fovea": nat.K_FOVEA, "full": nat.K_FULL, "ingest_rgb": nat.K_INGEST_RGB}[kernel]
         v = self._lib.agx_algorithmic_bytes(self._ctx, k)
         if v < 0:
             raise nat.AgxError(int(v), "algorithmic_bytes")
@@ -172,6 +172,13 @@ class ObsPipeline:
         return out, loc_out
 
     # ------------------------------------------------------------------ K0
+    def ingest_rgb(self, frames: torch.Tensor, cmd: torch.Tensor, gray_mode: int = nat.GRAY_CV15):
+        """frames u8[N,obs_h,obs_w,3] obs-sized RGB renders (DMC pixel path, reference dmc_env.py:175-186):
+        cv2 BGR2GRAY fixed point -> one append to the stack."""
+        pf = self._chk(frames, (self.num_envs,) + self.obs_size + (3,), torch.uint8, "frames")
+        pc = self._chk(cmd, (self.num_envs,), torch.uint8, "cmd")
+        nat.check(self._lib.agx_ingest_rgb(self._ctx, pf, pc, int(gray_mode), self._stream()), self._ctx)
+
     def observe_full(self, out: Optional[torch.Tensor] = None) -> torch.Tensor:
         if out is None:
             out = torch.empty(self.full_shape, dtype=torch.float32, device=self.device)

@@ -52,10 +52,7 @@ class AtariVecEnv:
         self.kind = kind
         self.num_envs = int(num_envs)
         self.obs_size = tuple(int(v) for v in args.obs_size)
-        if self.obs_size[0] != self.obs_size[1]:
-            # reference: cv2.resize(dsize=obs_size) yields (obs_size[1], obs_size[0]) and the assignment into
-            # frame_buffer raises (atari_env.py:74,121-128)
-            raise ValueError(f"obs_size {self.obs_size} must be square for Atari (cv2.resize takes (width, height))")
+        self._check_obs_size()
         self.frame_stack = int(args.frame_stack)
         self.action_repeat = int(args.action_repeat)
         dev = getattr(args, "device", None)
@@ -91,34 +88,10 @@ class AtariVecEnv:
             self.mask_out, self.resize_to_full = mask_out, resize_to_full
         self.pipe = ObsPipeline(**kw)
 
-        # host side: pinned staging for step frames and for reset frames, device twins
-        shape = (self.num_envs, 2, nat.RAW_H, nat.RAW_W, 3)
-        self._h_frames = torch.empty(shape, dtype=torch.uint8, pin_memory=True)
-        self._d_frames = torch.empty(shape, dtype=torch.uint8, device=self.device)
-        # reset screens get their own pinned buffer: the autoreset inside step() must not overwrite step
-        # screens whose asynchronous H2D copy may still be in flight
-        self._h_rframes = torch.empty((self.num_envs, 1, nat.RAW_H, nat.RAW_W, 3), dtype=torch.uint8, pin_memory=True)
-        self._h_rcmd = torch.empty((self.num_envs,), dtype=torch.uint8, pin_memory=True)
-        self._ev_copy = torch.cuda.Event()
-        self._ev_rcopy = torch.cuda.Event()
-        self._h_cmd = torch.empty((self.num_envs,), dtype=torch.uint8, pin_memory=True)
-        self._d_cmd = torch.empty((self.num_envs,), dtype=torch.uint8, device=self.device)
-        src = getattr(args, "frame_source", "ale")
-        if isinstance(src, str) and src.startswith("native"):
-            # C++ thread-per-core runner (libagx_runner.so): "native" = built-in scripted emulator,
-            # "native:ale" = real ALE through atari_py's libale_c.so
-            from .native_runner import NativeHostRunner
-            self.runner = NativeHostRunner(args, self.num_envs, frames=self._h_frames.numpy(),
-                                           workers=getattr(args, "num_workers", None), noop_fn=noop_fn,
-                                           env_offset=env_offset, backend="ale_c" if src == "native:ale" else "scripted")
-        else:
-            self.runner = AtariHostRunner(args, self.num_envs, frames=self._h_frames.numpy(),
-                                          workers=getattr(args, "num_workers", None), noop_fn=noop_fn,
-                                          env_offset=env_offset)
+        self._setup_source(args, noop_fn, env_offset)
 
         # spaces (reference atari_env.py:69-70, fov_env.py:125-142,243)
-        n_act = self.runner.num_actions
-        self.single_motor_space = Discrete(n_act)
+        self.single_motor_space = self._motor_space()
         full = (self.frame_stack,) + self.obs_size
         if kind == "base":
             self.single_action_space = self.single_motor_space
@@ -144,6 +117,47 @@ class AtariVecEnv:
         self._loc = torch.zeros((self.num_envs, 2), dtype=torch.int32, device=self.device)
         self._res = torch.zeros((self.num_envs, 2), dtype=torch.int32, device=self.device)
         self._was_reset = False
+
+    def _check_obs_size(self):
+        if self.obs_size[0] != self.obs_size[1]:
+            # reference: cv2.resize(dsize=obs_size) yields (obs_size[1], obs_size[0]) and the assignment into
+            # frame_buffer raises (atari_env.py:74,121-128)
+            raise ValueError(f"obs_size {self.obs_size} must be square for Atari (cv2.resize takes (width, height))")
+
+    def _motor_space(self):
+        return Discrete(self.runner.num_actions)
+
+    def _ingest(self):
+        self.pipe.ingest(self._d_frames, self._d_cmd)
+
+    def _extra_info(self, info):
+        return info
+
+    def _setup_source(self, args, noop_fn, env_offset):
+        # host side: pinned staging for step frames and for reset frames, device twins
+        shape = (self.num_envs, 2, nat.RAW_H, nat.RAW_W, 3)
+        self._h_frames = torch.empty(shape, dtype=torch.uint8, pin_memory=True)
+        self._d_frames = torch.empty(shape, dtype=torch.uint8, device=self.device)
+        # reset screens get their own pinned buffer: the autoreset inside step() must not overwrite step
+        # screens whose asynchronous H2D copy may still be in flight
+        self._h_rframes = torch.empty((self.num_envs, 1, nat.RAW_H, nat.RAW_W, 3), dtype=torch.uint8, pin_memory=True)
+        self._h_rcmd = torch.empty((self.num_envs,), dtype=torch.uint8, pin_memory=True)
+        self._ev_copy = torch.cuda.Event()
+        self._ev_rcopy = torch.cuda.Event()
+        self._h_cmd = torch.empty((self.num_envs,), dtype=torch.uint8, pin_memory=True)
+        self._d_cmd = torch.empty((self.num_envs,), dtype=torch.uint8, device=self.device)
+        src = getattr(args, "frame_source", "ale")
+        if isinstance(src, str) and src.startswith("native"):
+            # C++ thread-per-core runner (libagx_runner.so): "native" = built-in scripted emulator,
+            # "native:ale" = real ALE through atari_py's libale_c.so
+            from .native_runner import NativeHostRunner
+            self.runner = NativeHostRunner(args, self.num_envs, frames=self._h_frames.numpy(),
+                                           workers=getattr(args, "num_workers", None), noop_fn=noop_fn,
+                                           env_offset=env_offset, backend="ale_c" if src == "native:ale" else "scripted")
+        else:
+            self.runner = AtariHostRunner(args, self.num_envs, frames=self._h_frames.numpy(),
+                                          workers=getattr(args, "num_workers", None), noop_fn=noop_fn,
+                                          env_offset=env_offset)
 
     # ------------------------------------------------------------------ plumbing
     def close(self):
@@ -214,7 +228,7 @@ class AtariVecEnv:
             info["fov_loc"] = self._loc.cpu().numpy().astype(np.int64)
             if self.kind == "flexible":
                 info["fov_res"] = self._res.cpu().numpy().astype(np.int64)
-        return info
+        return self._extra_info(info)
 
     @staticmethod
     def _with_masks(info, n):
@@ -231,7 +245,7 @@ class AtariVecEnv:
         self._ev_rcopy.synchronize()
         cmd = self.runner.reset(out=self._h_rframes.numpy())
         self._upload_reset(cmd, None)
-        self.pipe.ingest(self._d_frames, self._d_cmd)
+        self._ingest()
         self.cumulative_reward[:] = 0
         self.ep_len[:] = 0
         if self.kind != "base":
@@ -271,7 +285,7 @@ class AtariVecEnv:
         else:
             reward, done, cmd, raw = self.runner.step(motor)
             self._upload(cmd)
-        self.pipe.ingest(self._d_frames, self._d_cmd)
+        self._ingest()
         obs = self._observe(sens, stype)
         self.ep_len += 1
         self.cumulative_reward += raw                   # unclipped, fov_env.py:62
@@ -292,7 +306,7 @@ class AtariVecEnv:
             self._ev_rcopy.synchronize()
             cmd2 = self.runner.reset(idx, out=self._h_rframes.numpy())
             self._upload_reset(cmd2, idx)
-            self.pipe.ingest(self._d_frames, self._d_cmd)
+            self._ingest()
             self.cumulative_reward[idx] = 0
             self.ep_len[idx] = 0
             mask = torch.from_numpy(done.astype(np.uint8)).to(self.device)
@@ -318,7 +332,7 @@ class AtariVecEnv:
         self._ev_rcopy.synchronize()
         cmd = self.runner.reset(idx, out=self._h_rframes.numpy())
         self._upload_reset(cmd, idx)
-        self.pipe.ingest(self._d_frames, self._d_cmd)
+        self._ingest()
         self.cumulative_reward[idx] = 0
         self.ep_len[idx] = 0
         m = np.zeros(n, np.uint8)

@@ -460,6 +460,8 @@ int64_t agx_algorithmic_bytes(const agx_ctx *ctx, int kernel_id) {
     switch (kernel_id) {
         case AGX_K_INGEST:   // two frames, only the source rows the vertical resize touches + one u8 slot
             return N * (2 * (int64_t)ctx->rows_touched * kRawRowBytes + px);
+        case AGX_K_INGEST_RGB:   // one obs-sized RGB render in, one u8 slot out
+            return N * px * 4;
         case AGX_K_FULL:
             return N * fs * px * 5;
         case AGX_K_FOVEA: {
@@ -558,6 +560,33 @@ int agx_ingest_gray(agx_ctx *ctx, const uint8_t *d_small, const uint8_t *d_cmd, 
     const int words = c.obs_h * c.obs_w / 4;
     hipLaunchKernelGGL(k_ingest_gray, dim3((words + kThreads - 1) / kThreads, c.num_envs), dim3(kThreads), 0,
                        S(stream), p);
+    AGX_HIP(ctx, hipGetLastError());
+    ctx->cur_head ^= 1;
+    return AGX_OK;
+}
+
+int agx_ingest_rgb(agx_ctx *ctx, const uint8_t *d_frames, const uint8_t *d_cmd, int gray_mode, void *stream) {
+    if (!ctx) return AGX_E_INVALID;
+    if (!d_frames || !d_cmd) return fail(ctx, AGX_E_INVALID, "agx_ingest_rgb: null buffer");
+    const agx_config &c = ctx->cfg;
+    DeviceGuard g(c.device);
+    IngestRgbParams p;
+    p.frames = d_frames;
+    p.cmd = d_cmd;
+    p.ring = ctx->ring;
+    p.head_in = ctx->head[ctx->cur_head];
+    p.head_out = ctx->head[ctx->cur_head ^ 1];
+    p.oh = c.obs_h;
+    p.ow = c.obs_w;
+    p.fs = c.frame_stack;
+    // cv2.cvtColor(rgb, COLOR_BGR2GRAY): channel 0 gets the blue weight (dmc_env.py:181-182 hands it an RGB render)
+    switch (gray_mode) {
+        case AGX_GRAY_CV15: p.k0 = 3735, p.k1 = 19235, p.k2 = 9798, p.shift = 15; break;   // OpenCV 4.x: BY15 GY15 RY15
+        case AGX_GRAY_CV14: p.k0 = 1868, p.k1 = 9617, p.k2 = 4899, p.shift = 14; break;    // OpenCV <= 3.x: B2Y G2Y R2Y
+        default: return fail(ctx, AGX_E_INVALID, "agx_ingest_rgb: unknown gray_mode %d", gray_mode);
+    }
+    const int words = c.obs_h * c.obs_w / 4;
+    hipLaunchKernelGGL(k_ingest_rgb, dim3((words + kThreads - 1) / kThreads, c.num_envs), dim3(kThreads), 0, S(stream), p);
     AGX_HIP(ctx, hipGetLastError());
     ctx->cur_head ^= 1;
     return AGX_OK;

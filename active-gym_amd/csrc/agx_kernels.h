@@ -3,6 +3,7 @@
 //
 //   k_ingest            K1  RGB -> ALE luminance -> OpenCV fixed-point bilinear -> 2-frame max -> u8 ring slot
 //   k_ingest_gray       K1' same append from already obs-sized gray frames
+//   k_ingest_rgb        K1b DMC front end: obs-sized RGB -> cv2 BGR2GRAY fixed point -> ring slot (no max, no resize)
 //   k_stack_u8 / k_full K0  ring -> stack order (u8 / f32 k/255)
 //   k_fovea_fixed       K2  clip/rint sensory action, crop, {raw | mask-out | bilinear upsample}
 //   k_fovea_generic     K3/K4 peripheral squeeze-expand + paste, flexible (ragged) fovea
@@ -708,6 +709,55 @@ __global__ __launch_bounds__(kThreads) void k_ingest_gray(IngestGrayParams p) {
         for (int k = 0; k < 4; ++k) m |= max((v >> (8 * k)) & 0xFF, (u >> (8 * k)) & 0xFF) << (8 * k);
         v = m;
     }
+    uint32_t *env = reinterpret_cast<uint32_t *>(p.ring) + (size_t)n * p.fs * words;
+    env[(size_t)slot * words + i] = v;
+    if (clear)
+        for (int s = 0; s < p.fs - 1; ++s) env[(size_t)s * words + i] = 0u;
+}
+
+// K1b (DMC pixel front end, reference dmc_env.py:175-186): frames are obs-sized RGB renders
+// u8[N][oh][ow][3]; gray = cv2.cvtColor(obs, COLOR_BGR2GRAY) - OpenCV's fixed-point weights with channel 0
+// taken as blue, exactly what the reference does to an RGB render - appended to the ring, no max-pool, no
+// resize.  One thread = 4 output pixels = 12 source bytes (three dwords, lane-contiguous).
+struct IngestRgbParams {
+    const uint8_t *frames;   // [N][oh][ow][3]
+    const uint8_t *cmd;      // [N]
+    uint8_t *ring;
+    const int32_t *head_in;
+    int32_t *head_out;
+    int32_t oh, ow, fs;
+    uint32_t k0, k1, k2;     // weights of channels 0,1,2; k0 + k1 + k2 == 1 << shift
+    uint32_t shift;
+};
+
+// grid = (ceil(oh*ow/4 / 256), N)
+__global__ __launch_bounds__(kThreads) void k_ingest_rgb(IngestRgbParams p) {
+    const int n = blockIdx.y;
+    const int words = (p.oh * p.ow) >> 2;
+    const int i = min((int)(blockIdx.x * kThreads + threadIdx.x), words - 1);
+    // the pixel loads go out before the per-env command / head loads they do not depend on
+    const uint32_t *src = reinterpret_cast<const uint32_t *>(p.frames) + ((size_t)n * words + i) * 3;
+    const uint32_t a = src[0], b = src[1], c = src[2];
+    const uint32_t cmd = p.cmd[n];
+    const int head = p.head_in[n];
+    const bool skip = (cmd & AGX_CMD_SKIP) != 0;
+    const bool clear = (cmd & AGX_CMD_CLEAR) != 0;
+    if (blockIdx.x == 0 && threadIdx.x == 0)
+        p.head_out[n] = skip ? head : (clear ? 0 : (head + 1 == p.fs ? 0 : head + 1));
+    if (skip || (int)(blockIdx.x * kThreads + threadIdx.x) >= words) return;
+    const uint32_t rnd = 1u << (p.shift - 1);
+    auto g = [&](uint32_t c0, uint32_t c1, uint32_t c2) {
+        return (mad_u24(c0, p.k0, mad_u24(c1, p.k1, mad_u24(c2, p.k2, rnd))) >> p.shift) & 0xFFu;
+    };
+    // bytes: a = c0 c1 c2 c0' | b = c1' c2' c0" c1" | c = c2" c0"' c1"' c2"'
+    uint32_t v = 0;
+    if ((cmd & AGX_CMD_NVALID_MASK) != 0) {
+        v = g(a & 0xFF, (a >> 8) & 0xFF, (a >> 16) & 0xFF);
+        v |= g(a >> 24, b & 0xFF, (b >> 8) & 0xFF) << 8;
+        v |= g((b >> 16) & 0xFF, b >> 24, c & 0xFF) << 16;
+        v |= g((c >> 8) & 0xFF, (c >> 16) & 0xFF, c >> 24) << 24;
+    }
+    const int slot = clear ? p.fs - 1 : head;
     uint32_t *env = reinterpret_cast<uint32_t *>(p.ring) + (size_t)n * p.fs * words;
     env[(size_t)slot * words + i] = v;
     if (clear)

@@ -81,6 +81,7 @@ extern "C" {
 #define AGX_K_INGEST      1
 #define AGX_K_FOVEA       2   /* the context's own fovea kernel (fixed / flexible / peripheral) */
 #define AGX_K_FULL        3
+#define AGX_K_INGEST_RGB  4   /* agx_ingest_rgb */
 
 typedef struct agx_ctx agx_ctx;
 
@@ -142,6 +143,15 @@ AGX_API int agx_ingest(agx_ctx *ctx, const uint8_t *d_frames, const uint8_t *d_c
  * [N][2][obs_h][obs_w] (sources that render at obs_size, e.g. the DMC path
  * dmc_env.py:175-186, and tests). */
 AGX_API int agx_ingest_gray(agx_ctx *ctx, const uint8_t *d_small, const uint8_t *d_cmd, void *stream);
+
+/* DMC pixel front end (reference dmc_env.py:175-186,211-234): d_frames u8 [N][obs_h][obs_w][3] are the
+ * obs-sized `physics.render()` images (RGB); the reference runs `cv2.cvtColor(obs, cv2.COLOR_BGR2GRAY)` on them,
+ * i.e. OpenCV's fixed-point luma with channel 0 weighted as blue, then `/255` and one append per step (no max-pool,
+ * no resize).  cmd as for agx_ingest (NVALID 0 appends zeros, CLEAR = _reset_buffer, SKIP).  gray_mode selects the
+ * OpenCV generation's coefficients (AGX_GRAY_*). */
+#define AGX_GRAY_CV15 0   /* OpenCV 4.x : (3735 c0 + 19235 c1 + 9798 c2 + 16384) >> 15 */
+#define AGX_GRAY_CV14 1   /* OpenCV <=3 : (1868 c0 +  9617 c1 + 4899 c2 +  8192) >> 14 */
+AGX_API int agx_ingest_rgb(agx_ctx *ctx, const uint8_t *d_frames, const uint8_t *d_cmd, int gray_mode, void *stream);
 
 /* ---- K0: base observation ----------------------------------------------
  * `np.stack(state_buffer, 0)` (atari_env.py:114,143), oldest -> newest, as

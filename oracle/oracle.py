@@ -531,3 +531,80 @@ class RingOracle:
     def full_state(self):
         """[N, fs, H, W] float64 holding float32-exact k/255 (atari_env.py:75,143)."""
         return u8_to_unit(self.stack_u8()).astype(np.float64)
+
+
+# ---------------------------------------------------------------------------
+# DMC pixel front end (reference dmc_env.py:175-186,199-240)
+# ---------------------------------------------------------------------------
+# Third-party arithmetic restated here: OpenCV ``cvtColor(..., COLOR_BGR2GRAY)`` for 8-bit input
+# (imgproc/src/color_rgb.simd.hpp, RGB2Gray<uchar>): fixed-point BT.601 luma, channel 0 weighted as blue.
+#   OpenCV 4.x : (c0*3735 + c1*19235 + c2*9798 + (1 << 14)) >> 15      (BY15, GY15, RY15, gray_shift = 15)
+#   OpenCV <=3 : (c0*1868 + c1*9617  + c2*4899 + (1 << 13)) >> 14      (B2Y,  G2Y,  R2Y,  yuv_shift  = 14)
+# PARITY UNPINNED: cv2 and dm_control are absent from the image and the reference holds no fixture for this
+# path; which generation applies depends on the installed OpenCV (the reference pins none, setup.py:14-19).
+CV_GRAY = {"cv15": (3735, 19235, 9798, 15), "cv14": (1868, 9617, 4899, 14)}
+
+
+def cv_bgr2gray_u8(img: np.ndarray, mode: str = "cv15") -> np.ndarray:
+    """u8[..., 3] -> u8[...]; the reference hands this an RGB render, so R gets the blue weight."""
+    img = np.asarray(img)
+    assert img.dtype == np.uint8 and img.shape[-1] == 3
+    k0, k1, k2, sh = CV_GRAY[mode]
+    c = img.astype(np.int64)
+    return ((c[..., 0] * k0 + c[..., 1] * k1 + c[..., 2] * k2 + (1 << (sh - 1))) >> sh).astype(np.uint8)
+
+
+class DMCEnvOracle:
+    """``DMCEnv`` (dmc_env.py:79-240) over any object with the dm_control surface the reference uses
+    (``reset/step -> time_step``, ``physics.render``, ``physics.get_state``, ``action_spec``)."""
+
+    def __init__(self, dmc_env, obs_size=(84, 84), frame_stack=3, action_repeat=4, clip_reward=False, camera_id=0,
+                 gray_mode="cv15"):
+        self.dmc_env, self.obs_size = dmc_env, tuple(obs_size)
+        self.frame_stack, self.action_repeat, self.clip_reward = frame_stack, action_repeat, clip_reward
+        self.camera_id, self.gray_mode = camera_id, gray_mode
+        self.state_buffer = collections.deque([], maxlen=frame_stack)
+        spec = dmc_env.action_spec()
+        z = np.zeros(int(np.prod(spec.shape)), dtype=np.float32)
+        self.true_low = (spec.minimum + z).astype(np.float32)            # _spec_to_box, dmc_env.py:27-47
+        self.true_high = (spec.maximum + z).astype(np.float32)
+
+    def _convert_action(self, action):                                  # dmc_env.py:166-173
+        action = np.asarray(action).astype(np.float64)
+        true_delta = self.true_high - self.true_low
+        norm_delta = np.float32(1.0) - np.float32(-1.0)
+        action = (action - np.float32(-1.0)) / norm_delta
+        action = action * true_delta + self.true_low
+        return action.astype(np.float32)
+
+    def _get_obs(self):                                                 # dmc_env.py:175-186
+        h, w = self.obs_size
+        obs = self.dmc_env.physics.render(height=h, width=w, camera_id=self.camera_id)
+        obs = cv_bgr2gray_u8(np.asarray(obs, dtype=np.uint8), self.gray_mode)
+        return obs.astype(np.float32) / np.float32(255.0)
+
+    def _info(self, ts, raw_reward=0):                                  # dmc_env.py:189-192
+        return {"internal_state": self.dmc_env.physics.get_state().copy(), "discount": ts.discount, "raw_reward": raw_reward}
+
+    def reset(self):                                                    # dmc_env.py:199-212
+        for _ in range(self.frame_stack):
+            self.state_buffer.append(np.zeros(self.obs_size))
+        ts = self.dmc_env.reset()
+        self.state_buffer.append(self._get_obs())
+        return np.stack(self.state_buffer, axis=0), self._info(ts)
+
+    def step(self, action):                                             # dmc_env.py:214-240
+        action = np.asarray(action)
+        assert action.shape == self.true_low.shape and np.all(action >= -1) and np.all(action <= 1)
+        action = self._convert_action(action)
+        assert np.all(action >= self.true_low) and np.all(action <= self.true_high)
+        reward = 0
+        for _ in range(self.action_repeat):
+            ts = self.dmc_env.step(action)
+            reward += ts.reward or 0
+            done = ts.last()
+            if done:
+                break
+        self.state_buffer.append(self._get_obs())
+        ret = np.sign(reward) if self.clip_reward else reward
+        return np.stack(self.state_buffer, axis=0), ret, done, False, self._info(ts, raw_reward=reward)

@@ -49,11 +49,17 @@ def _install_standins():
     gym = types.ModuleType("gymnasium")
 
     class Env:
-        pass
+        @property
+        def unwrapped(self):
+            return self
 
     class Wrapper(Env):
         def __init__(self, env):
             self.env = env
+
+        @property
+        def unwrapped(self):
+            return self.env.unwrapped
 
         def __getattr__(self, name):
             if name.startswith("__") or name == "env":
@@ -61,8 +67,23 @@ def _install_standins():
             return getattr(self.env, name)
 
     class Box:
+        """Data holder; with array bounds or a shape it also offers what dmc_env.py calls: seed / contains."""
+
         def __init__(self, low, high, shape=None, dtype=np.float32):
             self.low, self.high, self.shape, self.dtype = low, high, shape, dtype
+            if shape is not None or np.ndim(low) > 0:
+                shp = tuple(shape) if shape is not None else np.shape(low)
+                self.shape = shp
+                self.low = np.broadcast_to(np.asarray(low, dtype=dtype), shp).copy()
+                self.high = np.broadcast_to(np.asarray(high, dtype=dtype), shp).copy()
+
+        def seed(self, seed=None):
+            return [seed]
+
+        def contains(self, x):                  # gymnasium.spaces.Box.contains
+            x = np.asarray(x)
+            return bool(np.can_cast(x.dtype, self.dtype) and x.shape == self.shape
+                        and np.all(x >= self.low) and np.all(x <= self.high))
 
     class Discrete:
         def __init__(self, n):
@@ -78,6 +99,7 @@ def _install_standins():
     spaces = types.ModuleType("gymnasium.spaces")
     spaces.Box, spaces.Discrete, spaces.Dict = Box, Discrete, Dict
     gym.Env, gym.Wrapper, gym.spaces = Env, Wrapper, spaces
+    gym.Space = object                       # annotation only (dmc_env.py:27)
     sys.modules["gymnasium"] = gym
     sys.modules["gymnasium.spaces"] = spaces
 
@@ -130,9 +152,27 @@ def _install_standins():
         def release(self):
             self.entry["released"] = True
 
+    # cvtColor: the oracle's restatement of OpenCV 4.x BGR2GRAY (the DMC goldens pin CONTROL FLOW only)
+    sys.path.insert(0, REPO)
+    from oracle import oracle as _O
+    cv2.COLOR_BGR2GRAY = 6
+    cv2.cvtColor = lambda img, code: _O.cv_bgr2gray_u8(np.asarray(img), "cv15")
     cv2.VideoWriter = VideoWriter
     cv2.VideoWriter_fourcc = lambda *c: "".join(c)
     sys.modules["cv2"] = cv2
+
+    # dm_control.suite / dm_env.specs (dmc_env.py:15-16)
+    import fake_dmc
+    dmc = types.ModuleType("dm_control")
+    suite = types.ModuleType("dm_control.suite")
+    suite.load = lambda **kw: _STATE["next_dmc"](kw)
+    dmc.suite = suite
+    sys.modules["dm_control"], sys.modules["dm_control.suite"] = dmc, suite
+    dme = types.ModuleType("dm_env")
+    specs = types.ModuleType("dm_env.specs")
+    specs.Array, specs.BoundedArray = fake_dmc.Array, fake_dmc.BoundedArray
+    dme.specs = specs
+    sys.modules["dm_env"], sys.modules["dm_env.specs"] = dme, specs
 
     # atari_py
     ap = types.ModuleType("atari_py")
@@ -146,14 +186,14 @@ def _load_reference():
     pkg.__path__ = [os.path.join(REF, "active_gym")]
     sys.modules["refpkg"] = pkg
     mods = {}
-    for name in ("fov_env", "atari_env"):
+    for name in ("fov_env", "atari_env", "dmc_env"):
         spec = importlib.util.spec_from_file_location(
             f"refpkg.{name}", os.path.join(REF, "active_gym", f"{name}.py"))
         m = importlib.util.module_from_spec(spec)
         sys.modules[f"refpkg.{name}"] = m
         spec.loader.exec_module(m)
         mods[name] = m
-    return mods["fov_env"], mods["atari_env"]
+    return mods["fov_env"], mods["atari_env"], mods["dmc_env"]
 
 
 # ------------------------------------------------------------------ fovea goldens
@@ -500,13 +540,93 @@ def make_record(fov_env, gym):
         return [_record_case(fov_env, gym, k, k, 900 + i, tmp) for i, k in enumerate(("base", "fixed", "flex", "per"))]
 
 
+# ------------------------------------------------------------------ DMC control-flow goldens
+def _dmc_case(dmc_env, name, seed, obs=(12, 16), fs=3, ar=4, clip=False, steps=40, fixed_fov=False, episode_len=23):
+    """The reference's DMCEnv (+ RecordWrapper [+ FixedFovealEnv]) over tests/fake_dmc.ScriptedDMC: pins action
+    conversion, action repeat with early break, `reward or 0`, clipping, zero-fill + append, info keys."""
+    import fake_dmc
+    seen = {}
+
+    def load(kw):
+        seen.update(kw)
+        return fake_dmc.ScriptedDMC(seed, episode_len=episode_len)
+
+    _STATE["next_dmc"] = load
+    _STATE["antialias"] = True
+    kw = dict(frame_stack=fs, action_repeat=ar, clip_reward=clip)
+    if fixed_fov:
+        kw.update(fov_size=(4, 6), fov_init_loc=(1, 2), sensory_action_mode="absolute", resize_to_full=True)
+    args = dmc_env.DMCEnvArgs(domain_name="scripted", task_name="t", seed=seed, obs_size=tuple(obs), **kw)
+    env = dmc_env.DMCFixedFovealEnv(args) if fixed_fov else dmc_env.DMCBaseEnv(args)
+    assert seen["task_kwargs"]["random"] == seed
+    rng = np.random.default_rng(seed + 1)
+    motor = rng.uniform(-1, 1, size=(steps, 2)).astype(np.float32)
+    motor[3] = (-1.0, 1.0)
+    sens = rng.uniform(-2, 12, size=(steps, 2))
+    states, rewards, raws, dones, disc, internal, is_reset, ep_len, cum, fov_loc, cur = [], [], [], [], [], [], [], [], [], [], []
+
+    def push(s, r, d, info, rs):
+        states.append(np.asarray(s)); rewards.append(float(r)); dones.append(bool(d)); is_reset.append(rs)
+        raws.append(float(info["raw_reward"]))
+        disc.append(np.nan if info["discount"] is None else float(info["discount"]))
+        internal.append(np.asarray(info["internal_state"]).copy())
+        ep_len.append(info["ep_len"]); cum.append(float(info["reward"]))
+        fov_loc.append(np.asarray(info.get("fov_loc", np.zeros(2))))
+        cur.append(np.asarray(env.unwrapped.current_state).copy())
+
+    s, info = env.reset()
+    push(s, 0.0, False, info, True)
+    for t in range(steps):
+        if fixed_fov:
+            s, r, d, tr, info = env.step({"motor_action": motor[t], "sensory_action": sens[t]})
+        else:
+            s, r, d, tr, info = env.step(motor[t])
+        assert tr is False and sorted(k for k in info if k != "fov_loc") == ["discount", "ep_len", "internal_state", "raw_reward", "reward"]
+        push(s, r, d, info, False)
+        if d:
+            s, info = env.reset()
+            push(s, 0.0, False, info, True)
+    # quirk: the zero frames of _reset_buffer are float64, the rendered frames float32 (dmc_env.py:183,195-197), so
+    # np.stack yields float64 only while a zero frame is still in the deque
+    state_is_f64 = np.array([x.dtype == np.float64 for x in states])
+    assert all(x.dtype in (np.float32, np.float64) for x in states)
+    states = np.stack([x.astype(np.float64) for x in states])
+    base = env.unwrapped
+    rec = dict(seed=seed, state_is_f64=state_is_f64, obs_size=np.array(obs), frame_stack=fs, action_repeat=ar, clip_reward=clip, fixed_fov=fixed_fov,
+               episode_len=episode_len, motor=motor, sens=sens, rewards=np.array(rewards), raw_rewards=np.array(raws),
+               dones=np.array(dones), discount=np.array(disc), internal_state=np.stack(internal), is_reset=np.array(is_reset),
+               ep_len=np.array(ep_len, dtype=np.int64), cum_reward=np.array(cum), fov_loc=np.array(fov_loc, dtype=np.int64),
+               current_state=np.stack(cur), true_low=base._true_action_space.low, true_high=base._true_action_space.high,
+               obs_space_shape=np.array(base.observation_space.shape), state_space_shape=np.array(base.state_space.shape),
+               reward_range=np.array(base.reward_range))
+    if fixed_fov:
+        rec["states_f64"] = states
+    else:
+        u8 = np.rint(states * 255.0).astype(np.uint8)
+        assert np.array_equal((u8.astype(np.float32) / np.float32(255.0)).astype(np.float64), states)
+        rec["states_u8"] = u8
+    path = os.path.join(HERE, f"dmc_{name}.npz")
+    np.savez_compressed(path, **rec)
+    return path
+
+
+def make_dmc(dmc_env):
+    return [
+        _dmc_case(dmc_env, "ar4_fs3", seed=21),
+        _dmc_case(dmc_env, "ar4_clip", seed=22, clip=True),
+        _dmc_case(dmc_env, "ar1_fs2", seed=23, ar=1, fs=2, steps=30, episode_len=11),
+        _dmc_case(dmc_env, "ar3_fs4_break", seed=24, ar=3, fs=4, steps=30, episode_len=10),   # episode ends mid-repeat
+        _dmc_case(dmc_env, "fixedfov", seed=25, steps=30, fixed_fov=True),
+    ]
+
+
 def main():
     if not os.path.isdir(REF):
         raise SystemExit(f"reference checkout not found at {REF}; goldens are generated in the build container only")
     _install_standins()
-    fov_env, atari_env = _load_reference()
+    fov_env, atari_env, dmc_env = _load_reference()
     gym = sys.modules["gymnasium"]
-    paths = make_fovea(fov_env, gym) + make_atari(atari_env) + make_record(fov_env, gym)
+    paths = make_fovea(fov_env, gym) + make_atari(atari_env) + make_record(fov_env, gym) + make_dmc(dmc_env)
     total = 0
     for p in paths:
         sz = os.path.getsize(p)

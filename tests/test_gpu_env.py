@@ -230,12 +230,14 @@ def test_recording_buffer_keys(tmp_path):
     import active_gym
     args = _args(fov_size=(30, 30), fov_init_loc=(0, 0), sensory_action_mode="absolute", resize_to_full=True, record=True)
     env = active_gym.AtariFixedFovealEnv(args)
-    env.reset()
-    done = False
     n = 0
-    while not done and n < 400:
-        obs, r, done, _, info = env.step({"motor_action": 1, "sensory_action": np.array((5, 7))})
-        n += 1
+    while n < 3:                                 # an episode of at least 3 steps (a first-step terminal records no `done`)
+        env.reset()
+        done = False
+        n = 0
+        while not done and n < 400:
+            obs, r, done, _, info = env.step({"motor_action": 1, "sensory_action": np.array((5, 7))})
+            n += 1
     env.reset()                                  # moves the finished episode to prev_record_buffer
     rw = env.env
     buf = rw.prev_record_buffer
