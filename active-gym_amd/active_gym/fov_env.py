@@ -99,7 +99,11 @@ class FixedFovealEnv(_SingleEnv):
         self.action_space = Dict({"motor_action": base.action_space,
                                   "sensory_action": Box(low=self.sensory_action_space[0],
                                                         high=self.sensory_action_space[1], dtype=int)})
-        self.observation_space = core.single_observation_space
+        # declared exactly as the reference declares it (fov_env.py:132-142): the flexible env inherits the
+        # (fs,) + fov_size declaration for its crop mode although its crops are ragged (fov_env.py:283-286)
+        crop = self._KIND != "peripheral" and not (self.mask_out or self.resize_to_full)
+        self.observation_space = Box(low=-1., high=1., dtype=np.float32,
+                                     shape=(core.frame_stack,) + (tuple(self.fov_size) if crop else tuple(core.obs_size)))
         self.fov_loc = np.rint(np.array(self.fov_init_loc, copy=True)).astype(np.int32)   # fov_env.py:149-150
 
     def __getattr__(self, name):

@@ -540,6 +540,57 @@ def make_record(fov_env, gym):
         return [_record_case(fov_env, gym, k, k, 900 + i, tmp) for i, k in enumerate(("base", "fixed", "flex", "per"))]
 
 
+# ------------------------------------------------------------------ spaces / attributes
+def make_spaces(fov_env, gym):
+    """What each wrapper hands to gymnasium's space constructors and the attributes callers read
+    (fov_env.py:110-147,236-251,358-367), for square / non-square / relative / degenerate geometries."""
+    import json
+    out = {}
+
+    def space(sp):
+        if isinstance(sp, dict):
+            return {k: space(v) for k, v in sp.items()}
+        if hasattr(sp, "n"):
+            return {"type": "Discrete", "n": int(sp.n)}
+        lo, hi = np.asarray(sp.low), np.asarray(sp.high)
+        assert lo.min() == lo.max() and hi.min() == hi.max()              # uniform bounds everywhere in fov_env.py
+        return {"type": "Box", "low": lo.min().item(), "high": hi.min().item(),
+                "shape": None if sp.shape is None else list(sp.shape), "dtype": np.dtype(sp.dtype).name}
+
+    for kind in ("fixed", "flex", "per"):
+        for tag, obs, fov, mode, sas, rtf, mo in (
+                ("abs84", (84, 84), (30, 30), "absolute", None, True, False),
+                ("abs_nonsq", (36, 48), (10, 16), "absolute", None, False, False),
+                ("abs_mask", (36, 48), (10, 16), "absolute", None, False, True),
+                ("rel", (84, 84), (30, 30), "relative", (-10.0, 10.0), True, False),
+                ("rel_degenerate", (84, 84), (30, 30), "relative", (3, 3), False, False)):
+
+            class FakeBase(gym.Env):
+                def __init__(self):
+                    self.obs_size, self.frame_stack = tuple(obs), 4
+                    self.action_space = gym.spaces.Discrete(6)
+
+            args = _Args(fov_size=tuple(fov), fov_init_loc=(2.5, 3.5), sensory_action_mode=mode, sensory_action_space=sas,
+                         resize_to_full=rtf, mask_out=mo, peripheral_res=(9, 7))
+            base = fov_env.RecordWrapper(FakeBase(), args)
+            env = {"fixed": fov_env.FixedFovealEnv, "flex": fov_env.FlexibleFovealEnv,
+                   "per": fov_env.FixedFovealPeripheralEnv}[kind](base, args)
+            e = {"action_space": space(env.action_space), "observation_space": space(env.observation_space),
+                 "sensory_action_space": np.asarray(env.sensory_action_space).tolist(),
+                 "fov_loc": np.asarray(env.fov_loc).tolist(), "fov_loc_dtype": str(np.asarray(env.fov_loc).dtype),
+                 "fov_size": list(env.fov_size), "mask_out": bool(env.mask_out)}
+            if kind == "flex":
+                e["fov_res"] = np.asarray(env.fov_res).tolist()
+            if kind == "per":
+                e["peripheral_res"] = list(env.peripheral_res)
+                e["resize_to_full"] = bool(env.resize_to_full)
+            out[f"{kind}_{tag}"] = e
+    path = os.path.join(HERE, "spaces.json")
+    with open(path, "w") as f:
+        json.dump(out, f, indent=1, sort_keys=True)
+    return [path]
+
+
 # ------------------------------------------------------------------ DMC control-flow goldens
 def _dmc_case(dmc_env, name, seed, obs=(12, 16), fs=3, ar=4, clip=False, steps=40, fixed_fov=False, episode_len=23):
     """The reference's DMCEnv (+ RecordWrapper [+ FixedFovealEnv]) over tests/fake_dmc.ScriptedDMC: pins action
@@ -626,7 +677,7 @@ def main():
     _install_standins()
     fov_env, atari_env, dmc_env = _load_reference()
     gym = sys.modules["gymnasium"]
-    paths = make_fovea(fov_env, gym) + make_atari(atari_env) + make_record(fov_env, gym) + make_dmc(dmc_env)
+    paths = make_fovea(fov_env, gym) + make_atari(atari_env) + make_record(fov_env, gym) + make_dmc(dmc_env) + make_spaces(fov_env, gym)
     total = 0
     for p in paths:
         sz = os.path.getsize(p)

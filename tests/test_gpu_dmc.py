@@ -177,3 +177,25 @@ def test_dmc_vec_env_matches_oracle_with_autoreset(kind, gray):
                 assert np.array_equal(infos["fov_loc"][i], fov.fov_loc)
     assert n_done >= 5
     env.close()
+
+
+@pytest.mark.parametrize("kind", ["fixed", "flex", "per"])
+def test_dmc_spaces_non_square_match_reference(kind):
+    import json
+    import active_gym
+    gold = json.load(open(os.path.join(GOLD, "spaces.json")))
+    factory = {"fixed": active_gym.DMCFixedFovealEnv, "flex": active_gym.DMCFlexibleFovealEnv,
+               "per": active_gym.DMCFixedFovealPeripheralEnv}[kind]
+    for tag, rtf, mo in (("abs_nonsq", False, False), ("abs_mask", False, True)):
+        g = gold[f"{kind}_{tag}"]
+        env = factory(_args(3, obs_size=(36, 48), frame_stack=4, fov_size=(10, 16), fov_init_loc=(2.5, 3.5),
+                            sensory_action_mode="absolute", resize_to_full=rtf, mask_out=mo, peripheral_res=(9, 7)))
+        sa, gs = env.action_space["sensory_action"], g["action_space"]["sensory_action"]
+        assert float(np.min(sa.low)) == gs["low"] and float(np.max(sa.high)) == gs["high"] and np.dtype(sa.dtype).name == gs["dtype"]
+        assert env.action_space["motor_action"].shape == (2,)                       # DMC: Box(-1, 1, action_dim)
+        assert list(env.observation_space.shape) == g["observation_space"]["shape"]
+        assert np.asarray(env.sensory_action_space).tolist() == g["sensory_action_space"]
+        o, info = env.reset()
+        assert list(o.shape) == g["observation_space"]["shape"]
+        assert np.asarray(env.fov_loc).tolist() == g["fov_loc"] and bool(env.mask_out) == g["mask_out"]
+        env.close()

@@ -275,3 +275,41 @@ def test_bench_contract_json():
     c = d["cpu_baseline"]
     assert c["kind"] == "port" and c["cores"] >= 1 and c["value"] > 0 and "sample" in c
     assert abs(d["value"] - 64 * 8 / (d["ms_per_step"] * 8e-3)) / d["value"] < 1e-6
+
+
+@pytest.mark.parametrize("kind", ["fixed", "flex", "per"])
+def test_spaces_and_attributes_match_reference(kind):
+    """tests/golden/spaces.json: what the reference's wrappers hand to gymnasium's space constructors and the
+    attributes callers read (fov_env.py:110-147,236-251,358-367), incl. non-square, relative and degenerate cases."""
+    import json, os
+    import active_gym
+    gold = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "spaces.json")))
+    geo = {"abs84": ((84, 84), (30, 30), "absolute", None, True, False), "rel": ((84, 84), (30, 30), "relative", (-10.0, 10.0), True, False),
+           "rel_degenerate": ((84, 84), (30, 30), "relative", (3, 3), False, False)}        # Atari obs must be square
+    factory = {"fixed": active_gym.AtariFixedFovealEnv, "flex": active_gym.AtariFlexibleFovealEnv,
+               "per": active_gym.AtariFixedFovealPeripheralEnv}[kind]
+    for tag, (obs, fov, mode, sas, rtf, mo) in geo.items():
+        g = gold[f"{kind}_{tag}"]
+        args = _args(obs_size=obs, fov_size=fov, fov_init_loc=(2.5, 3.5), sensory_action_mode=mode, sensory_action_space=sas,
+                     resize_to_full=rtf, mask_out=mo, peripheral_res=(9, 7),
+                     frame_source=lambda a, i: ScriptedALE(seed=1, n_actions=6))
+        env = factory(args)
+        sp = env.action_space
+        assert sorted(sp.keys()) == sorted(g["action_space"].keys())
+        assert sp["motor_action"].n == g["action_space"]["motor_action"]["n"]
+        sa, gs = sp["sensory_action"], g["action_space"]["sensory_action"]
+        assert float(np.min(sa.low)) == gs["low"] and float(np.max(sa.high)) == gs["high"] and np.dtype(sa.dtype).name == gs["dtype"]
+        if kind == "flex":
+            assert sp["sensory_action_type"].n == 2
+        go = g["observation_space"]
+        assert list(env.observation_space.shape) == go["shape"] and np.dtype(env.observation_space.dtype).name == go["dtype"]
+        assert float(np.min(env.observation_space.low)) == go["low"] and float(np.max(env.observation_space.high)) == go["high"]
+        assert np.asarray(env.sensory_action_space).tolist() == g["sensory_action_space"]
+        env.reset()
+        assert np.asarray(env.fov_loc).tolist() == g["fov_loc"] and list(env.fov_size) == g["fov_size"]
+        assert bool(env.mask_out) == g["mask_out"]
+        if kind == "flex":
+            assert np.asarray(env.fov_res).tolist() == g["fov_res"]
+        if kind == "per":
+            assert list(env.peripheral_res) == g["peripheral_res"] and bool(env.resize_to_full) == g["resize_to_full"]
+        env.close()
