@@ -378,6 +378,12 @@ int agx_create(const agx_config *cfg, agx_ctx **out) {
         ctx->ingest_t = (forced_t == 128 || forced_t == 256) ? forced_t : 256;   // 8 WGs/CU whatever T: 256 fills the wave slots
         if (ow4 > 128) ctx->ingest_t = 256;
         ctx->band_rows = std::max(1, std::min(2 * (ctx->ingest_t / 40), ctx->ingest_t / ow4));
+        // tuning knob (bands per env).  Measured at N=1024, same box: 12 rows x 7 bands (3.5 rounds of 2048 resident
+        // workgroups) 46.0-46.7 us; 11 x 8 (4.0 rounds) 50-52; 10 x 9 53; and with wider workgroups whose grids are
+        // exact rounds - 320 thr x 14 rows, 384 x 18, 512 x 21 - 50.2 / 49.2 / 48.5 us: the half-empty last round is
+        // not what limits this kernel.
+        static const int forced_br = [] { const char *e = getenv("AGX_INGEST_BAND_ROWS"); return e ? atoi(e) : 0; }();
+        if (forced_br >= 1 && forced_br <= ctx->band_rows) ctx->band_rows = forced_br;
         static const int forced_br = [] { const char *e = getenv("AGX_INGEST_BAND_ROWS"); return e ? atoi(e) : 0; }();
         if (forced_br >= 1 && forced_br <= ctx->band_rows) ctx->band_rows = forced_br;     // tuning: bands per env
     }
