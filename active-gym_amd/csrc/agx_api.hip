@@ -384,8 +384,6 @@ int agx_create(const agx_config *cfg, agx_ctx **out) {
         // not what limits this kernel.
         static const int forced_br = [] { const char *e = getenv("AGX_INGEST_BAND_ROWS"); return e ? atoi(e) : 0; }();
         if (forced_br >= 1 && forced_br <= ctx->band_rows) ctx->band_rows = forced_br;
-        static const int forced_br = [] { const char *e = getenv("AGX_INGEST_BAND_ROWS"); return e ? atoi(e) : 0; }();
-        if (forced_br >= 1 && forced_br <= ctx->band_rows) ctx->band_rows = forced_br;     // tuning: bands per env
     }
     if (has_fovea(c)) {
         // _init_fov_loc: np.rint(fov_init_loc).astype(np.int32)  (not clipped)   fov_env.py:149-150
