@@ -113,3 +113,54 @@ def test_chunked_async_step_equals_blocking_step():
             assert np.array_equal(a.reset(d, out=oa), b.reset(d, out=ob)) and np.array_equal(oa, ob)
     with pytest.raises(RuntimeError, match="chunk"):
         b.step_wait(99)
+
+
+def test_ale_c_backend_through_a_stand_in_libale(tmp_path, monkeypatch):
+    """The dlopen backend end to end: tests/fake_libale.c exports atari_py's libale_c entry points over the scripted
+    emulator (real ALE is not in the image).  Checks the reference's five settings reach the library before loadROM
+    (atari_env.py:45-50), the minimal action set indirection (atari_env.py:51-52), and bit-exact agreement with the
+    Python runner."""
+    import subprocess
+    import sys
+    import types
+    _build()
+    so = str(tmp_path / "libale_c.so")
+    subprocess.run(["gcc", "-O2", "-shared", "-fPIC", os.path.join(REPO, "tests", "fake_libale.c"), "-o", so], check=True)
+    from active_gym import native_runner as nr
+    from active_gym.runner import AtariHostRunner
+    fake = types.ModuleType("atari_py")
+    fake.get_game_path = lambda game: f"/roms/{game}.bin"
+    monkeypatch.setitem(sys.modules, "atari_py", fake)
+    monkeypatch.setattr(nr, "_find_libale_c", lambda: (so, fake))
+    N = 4
+    common = dict(game="pong", seed=31, action_repeat=4, clip_reward=False, max_episode_length=108e3)
+    nv = nr.NativeHostRunner(_Args(**common), N, workers=2, noop_fn=lambda: 4, backend="ale_c")
+
+    class _ALE(LcgALE):                                  # same script, libale's action set
+        def getMinimalActionSet(self):
+            return [0, 1, 3, 4]
+
+    py = AtariHostRunner(_Args(frame_source=lambda a, i: _ALE(31 + i, 4, 3, 60, 15), **common), N, workers=1, noop_fn=lambda: 4)
+    assert nv.num_actions == 4
+    assert np.array_equal(py.reset(), nv.reset()) and np.array_equal(py.frames[:, 0], nv.frames[:, 0])
+    assert np.array_equal(py.lives, nv.lives) and (nv.lives > 0).all()       # -99 would mean the settings were wrong
+    rng = np.random.default_rng(4)
+    dones = 0
+    for step in range(80):
+        m = rng.integers(0, 4, N)
+        a, b = py.step(m), nv.step(m)
+        for x, y in zip(a, b):
+            assert np.array_equal(x, y), step
+        for i in range(N):
+            for s in range(int(a[2][i])):
+                assert np.array_equal(py.frames[i, s], nv.frames[i, s])
+        d = np.nonzero(a[1])[0]
+        dones += len(d)
+        if len(d):
+            ra = np.zeros((N, 1, 210, 160, 3), np.uint8); rb = np.zeros_like(ra)
+            assert np.array_equal(py.reset(d, out=ra), nv.reset(d, out=rb)) and np.array_equal(ra, rb)
+    assert dones >= 3
+    nv.close(); py.close()
+    with pytest.raises(RuntimeError, match="dlopen|symbol"):
+        monkeypatch.setattr(nr, "_find_libale_c", lambda: (str(tmp_path / "missing.so"), fake))
+        nr.NativeHostRunner(_Args(**common), 1, backend="ale_c")
