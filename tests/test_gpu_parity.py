@@ -4,6 +4,8 @@ at the benchmark's full size — through size-independent properties.
 
 Bars: integer / byte / index work bit-exact; float resize within 1e-5
 (BASELINE.json north_star)."""
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -496,7 +498,9 @@ def test_large_and_odd_batches(dev):
 # ---------------------------------------------------------------- fused step == ingest + fovea
 @pytest.mark.parametrize("geom", ["headline", "generic"])
 def test_step_fixed_equals_separate_calls(dev, geom, monkeypatch):
-    monkeypatch.setenv("AGX_STEP_FUSED", "1")       # read once per process by the library: set before the first call
+    # read once per process by the library: set before the first call (AGX_STEP_FUSED=2 in the environment selects
+    # the single-launch form for the whole test process)
+    monkeypatch.setenv("AGX_STEP_FUSED", os.environ.get("AGX_STEP_FUSED", "1"))
     N, fs = 37, 4
     rng = np.random.default_rng(77)
     fov = (30, 30) if geom == "headline" else (26, 34)
