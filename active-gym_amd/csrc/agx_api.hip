@@ -42,10 +42,28 @@ struct agx_ctx {
     int rows_touched = 0;
     int y_affine = 0, y_mul = 0, y_add = 0, y_shift = 0;   // see IngestParams
     int init_r = 0, init_c = 0;
+    // Tuning / testing knobs, read from the environment ONCE PER CONTEXT in agx_create (so one process can hold
+    // contexts of several variants and compare them: tests/test_gpu_parity.py::test_kernel_variants_bit_identical).
+    // Every variant is bit-identical to the default; the defaults are the measured-fastest forms.
+    struct Tune {
+        int ingest_t = 0;        // AGX_INGEST_T          128 | 256 threads per ingest workgroup
+        int band_rows = 0;       // AGX_INGEST_BAND_ROWS  output rows per ingest workgroup (<= the default)
+        int pipe_parts = 0;      // AGX_INGEST_PIPE       k_ingest_pipe with this many workgroups per env
+        int wave = 0;            // AGX_INGEST_WAVE       wave-private (barrier-free) ingest
+        int pair = 0;            // AGX_FOVEA_PAIR        two ring slots per K2 workgroup
+        int fused = 0;           // AGX_STEP_FUSED        agx_step_fixed as one heterogeneous launch + tail
+        int generic = 0;         // AGX_FOVEA_GENERIC     K3 / K4 through the generic fallback kernel
+    } tune;
     std::string err;
 };
 
 namespace {
+
+int env_int(const char *name, int dflt_if_set_empty = 1) {
+    const char *e = getenv(name);
+    if (!e) return 0;
+    return *e ? atoi(e) : dflt_if_set_empty;
+}
 
 thread_local std::string g_create_err;
 
@@ -314,6 +332,13 @@ int agx_create(const agx_config *cfg, agx_ctx **out) {
     agx_ctx *ctx = new (std::nothrow) agx_ctx;
     if (!ctx) return fail(nullptr, AGX_E_NOMEM, "out of host memory");
     ctx->cfg = c;
+    ctx->tune.ingest_t = env_int("AGX_INGEST_T");
+    ctx->tune.band_rows = env_int("AGX_INGEST_BAND_ROWS");
+    ctx->tune.pipe_parts = env_int("AGX_INGEST_PIPE");
+    ctx->tune.wave = env_int("AGX_INGEST_WAVE");
+    ctx->tune.pair = env_int("AGX_FOVEA_PAIR");
+    ctx->tune.fused = env_int("AGX_STEP_FUSED");
+    ctx->tune.generic = env_int("AGX_FOVEA_GENERIC");
     DeviceGuard g(c.device);
     int rc = AGX_OK;
     auto bail = [&](int code) {
@@ -374,7 +399,7 @@ int agx_create(const agx_config *cfg, agx_ctx **out) {
         // 2 * band_rows row jobs fit the T/40 loader groups x 4 iterations).  128-thread workgroups give
         // 16 independent workgroups per CU whose load / compute phases interleave (AGX_INGEST_T tunes).
         const int ow4 = c.obs_w / 4;
-        static const int forced_t = [] { const char *e = getenv("AGX_INGEST_T"); return e ? atoi(e) : 0; }();
+        const int forced_t = ctx->tune.ingest_t;
         ctx->ingest_t = (forced_t == 128 || forced_t == 256) ? forced_t : 256;   // 8 WGs/CU whatever T: 256 fills the wave slots
         if (ow4 > 128) ctx->ingest_t = 256;
         ctx->band_rows = std::max(1, std::min(2 * (ctx->ingest_t / 40), ctx->ingest_t / ow4));
@@ -382,7 +407,7 @@ int agx_create(const agx_config *cfg, agx_ctx **out) {
         // workgroups) 46.0-46.7 us; 11 x 8 (4.0 rounds) 50-52; 10 x 9 53; and with wider workgroups whose grids are
         // exact rounds - 320 thr x 14 rows, 384 x 18, 512 x 21 - 50.2 / 49.2 / 48.5 us: the half-empty last round is
         // not what limits this kernel.
-        static const int forced_br = [] { const char *e = getenv("AGX_INGEST_BAND_ROWS"); return e ? atoi(e) : 0; }();
+        const int forced_br = ctx->tune.band_rows;
         if (forced_br >= 1 && forced_br <= ctx->band_rows) ctx->band_rows = forced_br;
     }
     if (has_fovea(c)) {
@@ -523,11 +548,11 @@ int agx_ingest(agx_ctx *ctx, const uint8_t *d_frames, const uint8_t *d_cmd, void
     const IngestParams p = ingest_params(ctx, d_frames, d_cmd);
     const int bands = p.nbands;
     const size_t lds = ingest_lds(ctx);
-    static const int pipe_parts = [] { const char *e = getenv("AGX_INGEST_PIPE"); return e ? atoi(e) : 0; }();
+    const int pipe_parts = ctx->tune.pipe_parts;
     // wave-private form: needs the affine row form, band_rows = 4 * RPW with RPW * ow/4 <= 64 lanes and
     // 2 frames * RPW rows * 40 pieces <= 240 (RPW <= 3)
     // (measured equal to the barrier form at N=1024 - 46.5 vs 45.6 us - so it is opt-in: AGX_INGEST_WAVE=1)
-    static const bool want_wave = getenv("AGX_INGEST_WAVE") != nullptr;
+    const bool want_wave = ctx->tune.wave != 0;
     const int rpw = ctx->band_rows / 4;
     const bool wave_ok = want_wave && pipe_parts == 0 && ctx->ingest_t == 256 && ctx->y_affine && ctx->band_rows % 4 == 0 &&
                          rpw >= 1 && rpw <= 3 && rpw * (c.obs_w / 4) <= 64;
@@ -744,7 +769,7 @@ int agx_fovea_fixed(agx_ctx *ctx, const void *d_action, int action_dtype, const 
     } while (0)
     // two physical slots per workgroup (whole launch resident at once, second frame's load hidden): measured a tie
     // with the one-slot form at N=1024 (26.3 vs 25.8 us) - the launch is store-limited - so it is opt-in
-    static const int pair_knob = [] { const char *e = getenv("AGX_FOVEA_PAIR"); return e ? atoi(e) : 0; }();
+    const int pair_knob = ctx->tune.pair;
     const bool pair = c.out_mode == AGX_OUT_RESIZE && c.frame_stack % 2 == 0 && pair_knob == 1;
     if (pair) {
         const dim3 grid2(c.frame_stack / 2, c.num_envs);
@@ -777,7 +802,7 @@ int agx_step_fixed(agx_ctx *ctx, const uint8_t *d_frames, const uint8_t *d_cmd, 
     // The heterogeneous launch (ingest bands + fovea of the untouched slots in one grid, written slot after) is
     // bit-identical and measured a tie at N=1024 (69.3 vs 67.9 us per step: it fills the ingest's drain but its
     // second launch is one latency chain long), so the default is the two stand-alone launches.
-    static const bool fused = getenv("AGX_STEP_FUSED") != nullptr;              // tuning / testing knob
+    const bool fused = ctx->tune.fused != 0;                                    // tuning / testing knob
     if (c.out_mode != AGX_OUT_RESIZE || ctx->ingest_t != 256 || !fused || c.obs_h != c.obs_w) {
         // the two stand-alone launches, same results
         rc = agx_ingest(ctx, d_frames, d_cmd, stream);
@@ -824,7 +849,7 @@ int agx_fovea_peripheral(agx_ctx *ctx, const void *d_action, int action_dtype, c
     DeviceGuard g(c.device);
     const FovParams p = fov_params(ctx, d_action, action_dtype, nullptr, d_mask, d_obs, d_fov_loc, nullptr);
     const GeomR gr{c.obs_h, c.obs_w, c.fov_h, c.fov_w};
-    static const bool generic_only = getenv("AGX_FOVEA_GENERIC") != nullptr;       // tuning / testing knob
+    const bool generic_only = ctx->tune.generic != 0;                               // tuning / testing knob
     // the tuned kernel keeps A | B | C with C 16-byte aligned and one row sweep per 256 threads
     if (!generic_only && per2_lds(c) <= kMaxLds && c.per_w <= kThreads) {
         PerParams g;
@@ -867,7 +892,7 @@ int agx_fovea_flexible(agx_ctx *ctx, const void *d_action, int action_dtype, con
     DeviceGuard g(c.device);
     const FovParams p = fov_params(ctx, d_action, action_dtype, d_action_type, d_mask, d_obs, d_fov_loc, d_fov_res);
     const GeomR gr{c.obs_h, c.obs_w, c.fov_h, c.fov_w};
-    static const bool generic_only = getenv("AGX_FOVEA_GENERIC") != nullptr;       // tuning / testing knob
+    const bool generic_only = ctx->tune.generic != 0;                               // tuning / testing knob
     const size_t lds2 = flex2_lds(c, ctx->flex_tab_floats);
     if (!generic_only && lds2 <= kMaxLds) {
         FlexParams g;

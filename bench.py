@@ -41,7 +41,7 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-events", action="store_true", help="skip per-kernel HIP events in the timed region")
     ap.add_argument("--fused", action="store_true",
-                    help="fixed kind: use agx_step_fixed's heterogeneous launch (needs AGX_STEP_FUSED=1; measured a tie)")
+                    help="fixed kind: use agx_step_fixed's heterogeneous launch (sets AGX_STEP_FUSED=1; measured a tie)")
     ap.add_argument("--event-every", type=int, default=4,
                     help="bracket the kernels of every M-th timed step with HIP events (each record costs ~2-3 us of "
                          "stream time; M=1 measures every launch)")
@@ -197,6 +197,8 @@ def relaunch_under_torchrun(args):
 
 def main():
     args = parse()
+    if args.fused:
+        os.environ.setdefault("AGX_STEP_FUSED", "1")        # per-context tuning knob, read in agx_create
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))

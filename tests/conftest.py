@@ -11,8 +11,6 @@ for p in (REPO, os.path.join(REPO, "active-gym_amd"), os.path.join(REPO, "tests"
         sys.path.insert(0, p)
 
 GOLDEN = os.path.join(REPO, "tests", "golden")
-# libagx reads its tuning knobs once per process: opt into the fused-step launch so its parity test exercises it
-os.environ.setdefault("AGX_STEP_FUSED", "1")
 
 
 def pytest_configure(config):

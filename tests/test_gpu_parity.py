@@ -498,15 +498,15 @@ def test_large_and_odd_batches(dev):
 # ---------------------------------------------------------------- fused step == ingest + fovea
 @pytest.mark.parametrize("geom", ["headline", "generic"])
 def test_step_fixed_equals_separate_calls(dev, geom, monkeypatch):
-    # read once per process by the library: set before the first call (AGX_STEP_FUSED=2 in the environment selects
-    # the single-launch form for the whole test process)
-    monkeypatch.setenv("AGX_STEP_FUSED", os.environ.get("AGX_STEP_FUSED", "1"))
     N, fs = 37, 4
     rng = np.random.default_rng(77)
     fov = (30, 30) if geom == "headline" else (26, 34)
     kw = dict(num_envs=N, kind="fixed", obs_size=(84, 84), fov_size=fov, frame_stack=fs, resize_to_full=True,
               fov_init_loc=(3, 4), sensory_action_mode="relative", sensory_action_space=(-12.0, 12.0))
-    a, b = _pipe(**kw), _pipe(**kw)
+    monkeypatch.setenv("AGX_STEP_FUSED", "1")       # tuning knobs are read per context, in agx_create
+    a = _pipe(**kw)                                 # heterogeneous launch + tail
+    monkeypatch.delenv("AGX_STEP_FUSED")
+    b = _pipe(**kw)                                 # the default: two stand-alone launches
     ring = O.RingOracle(N, fs, (84, 84))
     orcs = [O.FixedFovealOracle(obs_size=(84, 84), fov_size=fov, fov_init_loc=(3, 4), sensory_action_mode="relative",
                                 sensory_action_space=(-12.0, 12.0), resize_to_full=True) for _ in range(N)]
@@ -535,6 +535,85 @@ def test_step_fixed_equals_separate_calls(dev, geom, monkeypatch):
         for i in range(N):
             if i % 5:
                 orcs[i].update_loc(act_np[i])
+
+
+# ---------------------------------------------------------------- every tuning variant == the default, bit for bit
+_KNOBS = ("AGX_INGEST_T", "AGX_INGEST_BAND_ROWS", "AGX_INGEST_PIPE", "AGX_INGEST_WAVE", "AGX_FOVEA_PAIR", "AGX_STEP_FUSED",
+          "AGX_FOVEA_GENERIC")
+
+
+@pytest.mark.parametrize("knob", [{"AGX_INGEST_T": "128"}, {"AGX_INGEST_BAND_ROWS": "7"}, {"AGX_INGEST_BAND_ROWS": "11"},
+                                  {"AGX_INGEST_PIPE": "2"}, {"AGX_INGEST_PIPE": "7"}, {"AGX_INGEST_WAVE": "1"},
+                                  {"AGX_FOVEA_PAIR": "1"}, {"AGX_STEP_FUSED": "1"},
+                                  {"AGX_INGEST_T": "128", "AGX_FOVEA_PAIR": "1"}], ids=lambda k: ",".join(f"{a}={b}" for a, b in k.items()))
+def test_kernel_variants_bit_identical(dev, knob, monkeypatch):
+    """The opt-in kernel forms (built, measured equal or slower, kept behind per-context knobs) must
+    reproduce the default kernels exactly: u8 ring, fov_loc and float observations."""
+    N, fs = 45, 4
+    kw = dict(num_envs=N, kind="fixed", obs_size=(84, 84), fov_size=(30, 30), frame_stack=fs, resize_to_full=True,
+              fov_init_loc=(0, 0), sensory_action_mode="absolute")
+    for k in _KNOBS:
+        monkeypatch.delenv(k, raising=False)
+    d = _pipe(**kw)
+    for k, v in knob.items():
+        monkeypatch.setenv(k, v)
+    v_ = _pipe(**kw)
+    rng = np.random.default_rng(11)
+    ties = _tie_pixels()
+    for step in range(7):
+        fr = rng.integers(0, 256, (N, 2, 210, 160, 3), dtype=np.uint8)
+        fr[step % N].reshape(-1, 3)[: len(ties)] = ties                       # exact .5 luminance ties in one env
+        frames = _t(fr, dev)
+        nvalid = rng.integers(0, 3, N)
+        clear = (rng.random(N) < 0.2).astype(np.uint8)
+        skip = (rng.random(N) < 0.15).astype(np.uint8)
+        nvalid[clear == 1] = 1
+        cmd = _t((nvalid | clear * 4 | skip * 8).astype(np.uint8), dev)
+        act = _t(rng.uniform(-5, 60, (N, 2)).astype(np.float32), dev)
+        d.ingest(frames, cmd)
+        od, ld = d.fovea(act)
+        if "AGX_STEP_FUSED" in knob:
+            ov, lv = v_.step_fixed(frames, cmd, act)
+        else:
+            v_.ingest(frames, cmd)
+            ov, lv = v_.fovea(act)
+        assert torch.equal(d.stack_u8(), v_.stack_u8()), (knob, step)
+        assert torch.equal(ld, lv) and torch.equal(od, ov), (knob, step)
+    d.close()
+    v_.close()
+
+
+@pytest.mark.parametrize("kind", ["peripheral", "flexible"])
+def test_generic_fallback_kernel_matches_tuned(dev, kind, monkeypatch):
+    """AGX_FOVEA_GENERIC routes K3 / K4 through k_fovea_generic (the fallback for geometries whose tables do not fit
+    the tuned kernels' LDS plan); same results up to float summation order."""
+    N, fs = 19, 4
+    kw = dict(num_envs=N, kind=kind, obs_size=(84, 84), fov_size=(30, 30), frame_stack=fs, resize_to_full=True,
+              fov_init_loc=(0, 0), sensory_action_mode="absolute")
+    if kind == "peripheral":
+        kw["peripheral_res"] = (20, 20)
+    monkeypatch.delenv("AGX_FOVEA_GENERIC", raising=False)
+    d = _pipe(**kw)
+    monkeypatch.setenv("AGX_FOVEA_GENERIC", "1")
+    g = _pipe(**kw)
+    rng = np.random.default_rng(12)
+    for step in range(6):
+        st = _t(rng.integers(0, 256, (N, fs, 84, 84), dtype=np.uint8), dev)
+        d.set_stack_u8(st)
+        g.set_stack_u8(st)
+        if kind == "flexible":
+            types = rng.integers(0, 2, N)
+            a = np.where(types[:, None] == 1, rng.integers(8, 80, (N, 2)), rng.integers(-5, 60, (N, 2))).astype(np.int64)
+            rd = d.fovea(_t(a, dev), action_type=_t(types.astype(np.int32), dev))
+            rg = g.fovea(_t(a, dev), action_type=_t(types.astype(np.int32), dev))
+        else:
+            a = rng.uniform(-5, 60, (N, 2)).astype(np.float32)
+            rd, rg = d.fovea(_t(a, dev)), g.fovea(_t(a, dev))
+        for x, y in zip(rd[1:], rg[1:]):
+            assert torch.equal(x, y)
+        assert (rd[0] - rg[0]).abs().max().item() <= 2e-6, step
+    d.close()
+    g.close()
 
 
 # ---------------------------------------------------------------- streams, several contexts, lifetime
