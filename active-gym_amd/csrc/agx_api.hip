@@ -188,11 +188,12 @@ size_t per2_tables(const agx_config &c) {
 
 size_t per2_lds(const agx_config &c) {
     const size_t raw = ((size_t)c.obs_h * c.obs_w + 15) & ~(size_t)15;
-    size_t ab = (size_t)c.obs_h * c.per_w + (size_t)c.per_h * c.per_w;
-    ab = (ab + 3) & ~(size_t)3;                      // keep C 16-byte aligned
+    // A[oh][pw] and C[ph][ow] share one region (C is written after A's last read), then B[ph][pw]
+    const size_t ac = (std::max((size_t)c.obs_h * c.per_w, (size_t)c.per_h * c.obs_w) + 3) & ~(size_t)3;
+    const size_t b = ((size_t)c.per_h * c.per_w + 3) & ~(size_t)3;
     // + the pass-1 and pass-3 tap tables ({lo,n} + zero-padded weights; bounded by the bucketed tap counts,
     //   which per2_tables() below computes the same way agx_create does)
-    return 1024 + raw + (ab + (size_t)c.per_h * c.obs_w) * sizeof(float) + per2_tables(c);
+    return 1024 + raw + (ac + b) * sizeof(float) + per2_tables(c);
 }
 
 // K4: one family = the taps of every window size r in [1, rmax] along one axis.

@@ -1493,7 +1493,7 @@ __global__ __launch_bounds__(kThreads) void k_fovea_generic(GeomR g, FovParams p
 // double, weights normalised, narrowed to f32): per output index {lo, n} and n weights.
 //   raw u8 frame --W squeeze--> A[oh][pw] --H squeeze--> B[ph][pw] --W expand--> C[ph][ow]
 //   --H expand, fused with the full-resolution fovea paste and the nontemporal store.
-// u8 -> f32 through the 256-entry LDS table.  ~27 KB LDS for 84/20: 5 workgroups per CU
+// u8 -> f32 through the 256-entry LDS table.  ~20 KB LDS for 84/20 (C aliases A): 8 workgroups per CU
 // (the generic kernel it replaces needed 43 KB and built its taps in f64 on the device).
 // ---------------------------------------------------------------------------------------------
 struct AxisTab {            // device pointers, one per pass
@@ -1521,13 +1521,13 @@ __global__ __launch_bounds__(kThreads) void k_fovea_peripheral2(PerParams g, Fov
     constexpr int MTR = MT > 0 ? MT : 1;
     const int fbytes = oh * ow, fwords = fbytes >> 2;
     const int mt1 = g.t[1].maxt, mt3 = g.t[3].maxt;
-    // LDS: lut[256] | raw[oh*ow] | A[oh][pw] | B[ph][pw] | C[ph][ow] | pass-1 table | pass-3 table
+    // LDS: lut[256] | raw[oh*ow] | A[oh][pw] aliased by C[ph][ow] | B[ph][pw] | pass-1 table | pass-3 table
     float *lut = reinterpret_cast<float *>(smem);
     unsigned char *raw = smem + 1024;
-    float *A = reinterpret_cast<float *>(raw + ((fbytes + 15) & ~15));
-    float *B = A + oh * pw;
-    float *C = A + ((oh * pw + ph * pw + 3) & ~3);                                 // 16-B aligned (as per2_lds)
-    int2 *ln1_s = reinterpret_cast<int2 *>(C + ph * ow);                           // [ph]
+    float *A = reinterpret_cast<float *>(raw + ((fbytes + 15) & ~15));             // 16-B aligned
+    float *C = A;                  // C reuses A's floats: A is dead once pass 1 has produced B (a barrier lies between)
+    float *B = A + ((max(oh * pw, ph * ow) + 3) & ~3);
+    int2 *ln1_s = reinterpret_cast<int2 *>(B + ((ph * pw + 3) & ~3));              // [ph]   (layout as per2_lds)
     float *w1_s = reinterpret_cast<float *>(ln1_s + ph);                           // [ph][mt1]
     int2 *ln3_s = reinterpret_cast<int2 *>(w1_s + ph * mt1);                       // [oh]
     float *w3_s = reinterpret_cast<float *>(ln3_s + oh);                           // [oh][mt3]
