@@ -14,7 +14,7 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 REPO = os.path.dirname(HERE)
 SRC = os.path.join(HERE, "csrc", "agx_api.hip")
-DEPS = [SRC] + [os.path.join(HERE, "csrc", f) for f in ("agx_kernels.h", "agx_taps.h")] + \
+DEPS = [SRC] + sorted(os.path.join(HERE, "csrc", f) for f in os.listdir(os.path.join(HERE, "csrc")) if f.endswith(".h")) + \
        [os.path.join(REPO, "include", "agx.h")]
 OUT_DIR = os.path.join(HERE, "lib")
 OUT = os.path.join(OUT_DIR, "libagx.so")

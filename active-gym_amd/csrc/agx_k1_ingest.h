@@ -1,0 +1,659 @@
+// agx_k1_ingest.h - K1: raw frames -> gray -> obs-sized -> ring slot (k_ingest and its opt-in forms, k_ingest_gray,
+// k_ingest_rgb).
+#pragma once
+#include "agx_common.h"
+
+namespace agx {
+
+// ---------------------------------------------------------------------------------------------
+// K1: ingest
+// ---------------------------------------------------------------------------------------------
+
+// ALE ColourPalette luminance: (uint8) round(r*0.2989 + g*0.5870 + b*0.1140) in C double.
+// The rational value (2989r+5870g+1140b)/10000 decides everything except exact .5 ties, where
+// the double evaluation sometimes lands below the tie (292 of 2^24 inputs); those are replayed
+// in double with the same operation order and no fused multiply-add.
+//
+// Instruction diet (K1 is issue-bound, not HBM-bound, unless this is tight):
+//   t   = 2989r + 5870g + 1140b + 5000 via two v_dot4_u32_u8 on the pixel dword
+//         (weights split as 256*(11,22,4) + (173,238,116)) and one v_lshl_add_u32;
+//   q   = floor(t / 10000) = v_mul_hi_u32_u24(t, ceil(2^37/1e4)) >> 5, exact for t < 2^22
+//         (t * eps / 2^37 < 1.9e-5 < the 1e-4 granularity of t/10000);
+//   tie = (q * 10000 == t), one v_mul_u32_u24 + v_cmp.
+constexpr uint32_t kLumWLo = 173u | (238u << 8) | (116u << 16);
+constexpr uint32_t kLumWHi = 11u | (22u << 8) | (4u << 16);
+
+__device__ __forceinline__ uint32_t ale_lum_px(uint32_t px /* r | g<<8 | b<<16 | any<<24 */, bool &tie) {
+    const uint32_t hi = __builtin_amdgcn_udot4(px, kLumWHi, 0u, false);
+    const uint32_t t = __builtin_amdgcn_udot4(px, kLumWLo, (hi << 8) + 5000u, false);
+    const uint32_t q = (uint32_t)(((uint64_t)(t & 0xFFFFFFu) * 13743896ull) >> 32) >> 5;
+    tie |= mul_u24(q, 10000u) == t;
+    return q;
+}
+
+// 12 bytes = 4 RGB pixels -> 4 luminance bytes packed little-endian; `tie` is raised when any of
+// them sits on an exact .5 tie (the caller re-does that piece with ale_lum_exact)
+__device__ __forceinline__ uint32_t lum4(uint32_t a, uint32_t b, uint32_t c, bool &tie) {
+    const uint32_t q0 = ale_lum_px(a, tie);
+    const uint32_t q1 = ale_lum_px(__builtin_amdgcn_alignbyte(b, a, 3), tie);
+    const uint32_t q2 = ale_lum_px(__builtin_amdgcn_alignbyte(c, b, 2), tie);
+    const uint32_t q3 = ale_lum_px(c >> 8, tie);
+    return q0 | (q1 << 8) | (q2 << 16) | (q3 << 24);
+}
+
+// exact-tie replay of one pixel in C double, ALE's operation order, no fused multiply-add
+__device__ __forceinline__ uint32_t ale_lum_exact(uint32_t r, uint32_t g, uint32_t b) {
+    const uint32_t t = 2989u * r + 5870u * g + 1140u * b + 5000u;
+    uint32_t q = t / 10000u;
+    if (t - q * 10000u == 0u) {
+#pragma clang fp contract(off)
+        const double x = ((double)r * 0.2989 + (double)g * 0.5870) + (double)b * 0.1140;
+        const double fl = floor(x);
+        q = (uint32_t)fl + (((x - fl) >= 0.5) ? 1u : 0u);
+    }
+    return q;
+}
+
+struct __attribute__((aligned(4))) U3 { uint32_t x, y, z; };
+
+struct IngestParams {
+    const uint8_t *frames;   // [N][2][210][160][3]
+    const uint8_t *cmd;      // [N]
+    uint8_t *ring;           // [N][fs][oh][ow]
+    const int32_t *head_in;  // [N]
+    int32_t *head_out;       // [N]
+    const int2 *xtab;        // [ow]  {x0 | x1<<16, a0 | a1<<16}
+    const int4 *ytab;        // [oh]  {y0, y1, b0, b1}
+    int32_t oh, ow, fs;
+    int32_t band_rows;       // output rows per workgroup (band_rows * ow/4 <= 256, band_rows <= 12)
+    int32_t nbands;          // ceil(oh / band_rows)
+    // y0(dy) == (dy * y_mul + y_add) >> y_shift and y1 == min(y0 + 1, raw_h - 1) for every dy (checked
+    // exhaustively against ytab at agx_create); lets the frame loads start without a table round trip.
+    int32_t y_affine, y_mul, y_add, y_shift;
+    unsigned long long *stamps;   // diagnostic builds only (AGX_STAMPS): [workgroup][wave][8] records
+};
+
+
+// grid = (bands, N), block = T threads (T = 128 or 256).  Per workgroup: the two source rows of each
+// of its output rows, for both frames, go HBM -> registers (12-byte / 4-pixel pieces, lane-contiguous)
+// -> luminance -> LDS; then each thread produces 4 adjacent output pixels and stores one dword.
+// LDS gray layout: [frame][dyl][x][2] — the vertical pair (row y0, row y1) of one source column is
+// one aligned u16, so the bilinear taps of an output pixel are two ds_read_u16.
+// Measured floor of this access shape with no arithmetic at all: ~30 us at N=1024 (tools/membench.hip).
+template <int T>
+__device__ __forceinline__ void ingest_band(const IngestParams &p, const int band, const int n, unsigned char *smem) {
+    const int tid = threadIdx.x;
+    AGX_STAMP(0);
+    const int BR = p.band_rows;
+    const int dy0 = band * BR;
+    const int rows = min(BR, p.oh - dy0);
+    int4 *ytab_s = reinterpret_cast<int4 *>(smem);                      // [BR]
+    int2 *xtab_s = reinterpret_cast<int2 *>(smem + sizeof(int4) * BR);    // [ow]
+    unsigned char *gray = smem + sizeof(int4) * BR + sizeof(int2) * p.ow; // [2][BR][160][2]
+    const int ow4 = p.ow >> 2;
+    if (!p.y_affine) {                       // general geometry: source rows come from the table
+        if (tid < rows) ytab_s[tid] = p.ytab[dy0 + tid];
+        __syncthreads();
+    }
+
+    // phase 1: thread = (piece g4 of 40, row group rg of T/40); row job rj = rg + RG*it is (frame,
+    // output row); it loads both source rows of that output row, 4 pixels wide -> 8 gray bytes in LDS.
+    // The loads go out FIRST and unconditionally, as if both frames were wanted (stamps showed 40 % of
+    // a wave's life spent waiting for the per-env command byte before its first frame load): the
+    // command / ring-head scalar loads then complete underneath them; `skip` and `nvalid` only gate
+    // what is written.  (A skipped env costs its reads; sparse launches are rare and host-bound.)
+    constexpr int G4 = kRawW / 4;                                         // 40 four-pixel pieces per row
+    constexpr int RG = T / G4;                                            // row groups: 6 (T=256) / 3 (T=128)
+    constexpr int kIter = 4;                                              // 2 frames * band_rows / RG
+    const int rg = tid / G4, g4 = tid - rg * G4;
+    const uint8_t *fbase = p.frames + (size_t)n * 2 * kRawFrameBytes;     // wave-uniform base
+    const uint32_t col = g4 * 12;
+    int nvalid = 2;                                                       // speculative until cmd arrives
+    auto row_offsets = [&](int it, uint32_t &o0, uint32_t &o1, int &d) {
+        const int nrj = max(nvalid, 1) * rows;
+        const int rj_raw = rg + RG * it;
+        const int rj = min(rj_raw, nrj - 1);
+        const int f = rj >= rows ? 1 : 0;                                 // nvalid <= 2
+        const int dyl = rj - f * rows;
+        int y0, y1;
+        if (p.y_affine) {
+            y0 = (int)(mul_u24((uint32_t)(dy0 + dyl), (uint32_t)p.y_mul) + (uint32_t)p.y_add) >> p.y_shift;
+            y1 = min(y0 + 1, kRawH - 1);
+        } else {
+            const int4 yt = ytab_s[dyl];
+            y0 = yt.x;
+            y1 = yt.y;
+        }
+        const uint32_t fo = f * kRawFrameBytes + col;                     // 32-bit lane offsets
+        o0 = mad_u24((uint32_t)y0, kRawRowBytes, fo);
+        o1 = mad_u24((uint32_t)y1, kRawRowBytes, fo);
+        d = (rj_raw < nvalid * rows && rg < RG) ? ((f * BR + dyl) * kRawW + g4 * 4) * 2 : -1;
+    };
+    U3 w0[kIter], w1[kIter];
+    int dst[kIter];
+#pragma unroll
+    for (int it = 0; it < kIter; ++it) {
+        uint32_t o0, o1;
+        row_offsets(it, o0, o1, dst[it]);
+        w0[it] = *reinterpret_cast<const U3 *>(fbase + o0);
+        w1[it] = *reinterpret_cast<const U3 *>(fbase + o1);
+    }
+    const uint32_t cmd = uniform_load_u8(p.cmd + n);
+    const int head = uniform_load_i32(p.head_in + n);
+    const bool skip = (cmd & AGX_CMD_SKIP) != 0;
+    const bool clear = (cmd & AGX_CMD_CLEAR) != 0;
+    if (band == 0 && tid == 0) p.head_out[n] = skip ? head : (clear ? 0 : (head + 1 == p.fs ? 0 : head + 1));
+    if (skip) return;
+    nvalid = min((int)(cmd & AGX_CMD_NVALID_MASK), 2);
+    const int slot = clear ? p.fs - 1 : head;
+    const int nrj = nvalid * rows;
+    if (nrj > 0) {
+#pragma unroll
+        for (int it = 0; it < kIter; ++it)                                // frame-1 jobs are void when nvalid == 1
+            if (rg + RG * it >= nrj) dst[it] = -1;
+        AGX_STAMP(1);
+        // the phase-2 tables are requested AFTER the frame pieces (vmcnt retires in order, so waiting
+        // for them later costs nothing) and parked in LDS once the luminance work is done
+        const int4 yt_own = p.ytab[dy0 + min(tid, rows - 1)];
+        const int2 xt_own = p.xtab[min(tid, p.ow - 1)];
+        uint32_t tie_its = 0;
+#pragma unroll
+        for (int it = 0; it < kIter; ++it) {
+            bool tie = false;
+            const uint32_t top = lum4(w0[it].x, w0[it].y, w0[it].z, tie);
+            const uint32_t bot = lum4(w1[it].x, w1[it].y, w1[it].z, tie);
+            if (dst[it] >= 0) {
+                uint2 v;                                                  // t0 b0 t1 b1 | t2 b2 t3 b3
+                v.x = __builtin_amdgcn_perm(bot, top, 0x05010400u);
+                v.y = __builtin_amdgcn_perm(bot, top, 0x07030602u);
+                *reinterpret_cast<uint2 *>(gray + dst[it]) = v;
+                tie_its |= tie ? (1u << it) : 0u;
+            }
+        }
+        if (__builtin_expect(tie_its != 0, 0)) {
+            // about 1e-4 of random pixels sit on an exact .5 tie: redo those pieces byte by byte with
+            // the exact rule.  The source bytes are re-read (L2 hits) so that the fast path does not
+            // have to keep 24 registers alive for this branch.
+#pragma nounroll
+            for (int it = 0; it < kIter; ++it) {
+                if (!((tie_its >> it) & 1u)) continue;
+                uint32_t o0, o1;
+                int d;
+                row_offsets(it, o0, o1, d);
+                const U3 a = *reinterpret_cast<const U3 *>(fbase + o0);   // one round trip, then registers only
+                const U3 b = *reinterpret_cast<const U3 *>(fbase + o1);
+#pragma nounroll
+                for (int j = 0; j < 8; ++j) {
+                    const bool which = j & 1;
+                    const int k = j >> 1;
+                    const uint32_t x = which ? b.x : a.x, y = which ? b.y : a.y, z = which ? b.z : a.z;
+                    const uint64_t lo = (uint64_t)x | ((uint64_t)y << 32);
+                    const uint64_t hi = (uint64_t)y | ((uint64_t)z << 32);
+                    const uint32_t px = (uint32_t)(k < 2 ? (lo >> (24 * k)) : (hi >> (24 * k - 32)));
+                    gray[d + j] = (unsigned char)ale_lum_exact(px & 0xFF, (px >> 8) & 0xFF, (px >> 16) & 0xFF);
+                }
+            }
+        }
+        if (tid < rows) ytab_s[tid] = yt_own;
+        if (tid < p.ow) xtab_s[tid] = xt_own;
+        for (int i = tid + T; i < p.ow; i += T) xtab_s[i] = p.xtab[i];
+    }
+    AGX_STAMP(2);
+    __syncthreads();
+    AGX_STAMP(3);
+
+    // phase 2: OpenCV fixed-point bilinear + max over the sampled frames
+    if (tid < rows * ow4) {
+        const int dyl = tid / ow4, xq = tid - dyl * ow4;
+        const int dy = dy0 + dyl;
+        uint32_t b0 = 0, b1 = 0;
+        int4 xt01 = make_int4(0, 0, 0, 0), xt23 = xt01;
+        if (nvalid) {
+            const int4 yt = ytab_s[dyl];
+            b0 = (uint32_t)yt.z;
+            b1 = (uint32_t)yt.w;
+            xt01 = *reinterpret_cast<const int4 *>(xtab_s + xq * 4);
+            xt23 = *reinterpret_cast<const int4 *>(xtab_s + xq * 4 + 2);
+        }
+        uint32_t packed = 0;
+        const int xi[4] = {xt01.x, xt01.z, xt23.x, xt23.z};
+        const int xa[4] = {xt01.y, xt01.w, xt23.y, xt23.w};
+        const unsigned char *row0 = gray + mul_u24((uint32_t)dyl, kRawW * 2);      // frame 0, this output row
+        const uint32_t fstride = (uint32_t)BR * kRawW * 2;                         // wave-uniform
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const uint32_t x0 = xi[k] & 0xFFFF, x1 = (uint32_t)xi[k] >> 16;
+            const uint32_t a0 = xa[k] & 0xFFFF, a1 = (uint32_t)xa[k] >> 16;
+            uint32_t best = 0;
+            for (int f = 0; f < nvalid; ++f) {
+                const uint16_t *row = reinterpret_cast<const uint16_t *>(row0 + f * fstride);
+                const uint32_t p0 = row[x0], p1 = row[x1];               // lo byte: row y0, hi byte: row y1
+                const uint32_t h0 = mad_u24(p1 & 0xFF, a1, mul_u24(p0 & 0xFF, a0));
+                const uint32_t h1 = mad_u24(p1 >> 8, a1, mul_u24(p0 >> 8, a0));
+                const uint32_t v = (((mul_u24(b0, h0 >> 4) >> 16) + (mul_u24(b1, h1 >> 4) >> 16) + 2) >> 2) & 0xFF;
+                best = max(best, v);
+            }
+            packed |= best << (8 * k);
+        }
+        const uint32_t fsz = (uint32_t)p.oh * p.ow;
+        uint8_t *env = p.ring + (size_t)n * p.fs * fsz;                            // wave-uniform
+        const uint32_t off = mad_u24((uint32_t)dy, (uint32_t)p.ow, (uint32_t)xq * 4);
+        *reinterpret_cast<uint32_t *>(env + (slot * fsz + off)) = packed;
+        if (clear)
+            for (int s = 0; s < p.fs - 1; ++s) *reinterpret_cast<uint32_t *>(env + (s * fsz + off)) = 0u;
+    }
+    AGX_STAMP(4);
+}
+
+template <int T>
+__global__ __launch_bounds__(T) void k_ingest(IngestParams p) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    ingest_band<T>(p, blockIdx.x, blockIdx.y, smem);
+}
+
+// ---------------------------------------------------------------------------------------------
+// K1, wave-private form (opt-in, AGX_INGEST_WAVE=1): grid = (bands, N), block = 256, but
+// the 4 waves of a workgroup never meet.  Wave w owns RPW = band_rows/4 output rows end to end:
+// it loads their source rows for both frames (60 of its 64 lanes x 4 pieces = 240 twelve-byte
+// pieces = 3 rows x 2 frames x 40), turns them into gray bytes in ITS slice of LDS, and produces its
+// own 3 x ow/4 (= 63) output dwords.  No __syncthreads: LDS traffic of one wave is ordered by the
+// hardware, so only a wavefront-scope fence separates the phases.  (s_memtime stamps of the
+// barrier version: 16 % of a wave's life waiting at the barrier, on top of inter-wave skew.)
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(kThreads) void k_ingest_wave(IngestParams p) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    constexpr int T = kThreads;                                           // (AGX_STAMP uses T)
+    (void)T;
+    const int n = blockIdx.y, band = blockIdx.x, tid = threadIdx.x;
+    const int wave = tid >> 6, lane = tid & 63;
+    AGX_STAMP(0);
+    const int BR = p.band_rows, RPW = BR >> 2;                            // rows per wave (3 for 84x84)
+    const int dy0 = band * BR + wave * RPW;                               // first output row of this wave
+    const int rows = max(0, min(RPW, p.oh - dy0));
+    const int ow4 = p.ow >> 2;
+    // per-wave LDS slice: xtab[ow] int2 | gray[2][RPW][160][2]
+    const int slice = (int)sizeof(int2) * p.ow + 2 * RPW * kRawW * 2;
+    unsigned char *mine = smem + wave * ((slice + 15) & ~15);
+    int2 *xtab_s = reinterpret_cast<int2 *>(mine);
+    unsigned char *gray = mine + sizeof(int2) * p.ow;
+
+    constexpr int G4 = kRawW / 4, LPI = 60, kIter = 4;                    // 60 lanes x 4 = 240 pieces
+    const uint8_t *fbase = p.frames + (size_t)n * 2 * kRawFrameBytes;
+    int nvalid = 2;                                                       // speculative until cmd arrives
+    auto piece = [&](int it, uint32_t &o0, uint32_t &o1, int &d) {
+        const int ntask = max(nvalid, 1) * max(rows, 1) * G4;
+        const int t_raw = it * LPI + lane;
+        const int task = min(t_raw, ntask - 1);
+        const int rj = task / G4, g4 = task - rj * G4;                    // rj = f * rows + dl
+        const int f = rj >= rows ? 1 : 0;
+        const int dl = rj - f * rows;
+        const int dy = min(dy0 + dl, p.oh - 1);
+        const int y0 = (int)(mul_u24((uint32_t)dy, (uint32_t)p.y_mul) + (uint32_t)p.y_add) >> p.y_shift;
+        const int y1 = min(y0 + 1, kRawH - 1);
+        const uint32_t fo = f * kRawFrameBytes + g4 * 12;
+        o0 = mad_u24((uint32_t)y0, kRawRowBytes, fo);
+        o1 = mad_u24((uint32_t)y1, kRawRowBytes, fo);
+        d = (lane < LPI && t_raw < nvalid * rows * G4) ? ((f * RPW + dl) * kRawW + g4 * 4) * 2 : -1;
+    };
+    U3 w0[kIter], w1[kIter];
+    int dst[kIter];
+#pragma unroll
+    for (int it = 0; it < kIter; ++it) {
+        uint32_t o0, o1;
+        piece(it, o0, o1, dst[it]);
+        w0[it] = *reinterpret_cast<const U3 *>(fbase + o0);
+        w1[it] = *reinterpret_cast<const U3 *>(fbase + o1);
+    }
+    // phase-2 taps: requested after the frame pieces, parked in this wave's LDS slice
+    const int dl2 = lane / ow4, xq = lane - dl2 * ow4;
+    const bool p2 = lane < rows * ow4;
+    const int4 yt2 = p.ytab[min(dy0 + dl2, p.oh - 1)];
+    int2 xt_own[2];
+    xt_own[0] = p.xtab[min(lane, p.ow - 1)];
+    xt_own[1] = p.xtab[min(lane + 64, p.ow - 1)];
+    const uint32_t cmd = uniform_load_u8(p.cmd + n);
+    const int head = uniform_load_i32(p.head_in + n);
+    const bool skip = (cmd & AGX_CMD_SKIP) != 0;
+    const bool clear = (cmd & AGX_CMD_CLEAR) != 0;
+    if (band == 0 && tid == 0) p.head_out[n] = skip ? head : (clear ? 0 : (head + 1 == p.fs ? 0 : head + 1));
+    if (skip || rows == 0) return;
+    nvalid = min((int)(cmd & AGX_CMD_NVALID_MASK), 2);
+    const int slot = clear ? p.fs - 1 : head;
+    AGX_STAMP(1);
+    if (nvalid > 0) {
+        uint32_t tie_its = 0;
+#pragma unroll
+        for (int it = 0; it < kIter; ++it) {
+            bool tie = false;
+            const uint32_t top = lum4(w0[it].x, w0[it].y, w0[it].z, tie);
+            const uint32_t bot = lum4(w1[it].x, w1[it].y, w1[it].z, tie);
+            if (it * LPI + lane >= nvalid * rows * G4) dst[it] = -1;      // frame-1 pieces are void when nvalid == 1
+            if (dst[it] >= 0) {
+                uint2 v;                                                  // t0 b0 t1 b1 | t2 b2 t3 b3
+                v.x = __builtin_amdgcn_perm(bot, top, 0x05010400u);
+                v.y = __builtin_amdgcn_perm(bot, top, 0x07030602u);
+                *reinterpret_cast<uint2 *>(gray + dst[it]) = v;
+                tie_its |= tie ? (1u << it) : 0u;
+            }
+        }
+        if (__builtin_expect(tie_its != 0, 0)) {                          // exact .5 luminance ties, ~1e-4 of pixels
+#pragma nounroll
+            for (int it = 0; it < kIter; ++it) {
+                if (!((tie_its >> it) & 1u)) continue;
+                uint32_t o0, o1;
+                int d;
+                piece(it, o0, o1, d);
+                const U3 a = *reinterpret_cast<const U3 *>(fbase + o0);
+                const U3 b = *reinterpret_cast<const U3 *>(fbase + o1);
+#pragma nounroll
+                for (int j = 0; j < 8; ++j) {
+                    const bool which = j & 1;
+                    const int k = j >> 1;
+                    const uint32_t x = which ? b.x : a.x, y = which ? b.y : a.y, z = which ? b.z : a.z;
+                    const uint64_t lo = (uint64_t)x | ((uint64_t)y << 32);
+                    const uint64_t hi = (uint64_t)y | ((uint64_t)z << 32);
+                    const uint32_t px = (uint32_t)(k < 2 ? (lo >> (24 * k)) : (hi >> (24 * k - 32)));
+                    gray[d + j] = (unsigned char)ale_lum_exact(px & 0xFF, (px >> 8) & 0xFF, (px >> 16) & 0xFF);
+                }
+            }
+        }
+        if (lane < p.ow) xtab_s[lane] = xt_own[0];
+        if (lane + 64 < p.ow) xtab_s[lane + 64] = xt_own[1];
+        for (int i = lane + 128; i < p.ow; i += 64) xtab_s[i] = p.xtab[i];
+    }
+    AGX_STAMP(2);
+    // this wave's LDS writes are consumed by other lanes of the SAME wave only
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    AGX_STAMP(3);
+    if (p2) {
+        const int dy = dy0 + dl2;
+        uint32_t packed = 0;
+        if (nvalid > 0) {
+            const uint32_t b0 = (uint32_t)yt2.z, b1 = (uint32_t)yt2.w;
+            const int4 xt01 = *reinterpret_cast<const int4 *>(xtab_s + xq * 4);
+            const int4 xt23 = *reinterpret_cast<const int4 *>(xtab_s + xq * 4 + 2);
+            const int xi[4] = {xt01.x, xt01.z, xt23.x, xt23.z};
+            const int xa[4] = {xt01.y, xt01.w, xt23.y, xt23.w};
+            const unsigned char *row0 = gray + mul_u24((uint32_t)dl2, kRawW * 2);
+            const uint32_t fstride = (uint32_t)RPW * kRawW * 2;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const uint32_t x0 = xi[k] & 0xFFFF, x1 = (uint32_t)xi[k] >> 16;
+                const uint32_t a0 = xa[k] & 0xFFFF, a1 = (uint32_t)xa[k] >> 16;
+                uint32_t best = 0;
+                for (int f = 0; f < nvalid; ++f) {
+                    const uint16_t *row = reinterpret_cast<const uint16_t *>(row0 + f * fstride);
+                    const uint32_t p0 = row[x0], p1 = row[x1];           // lo byte: row y0, hi byte: row y1
+                    const uint32_t h0 = mad_u24(p1 & 0xFF, a1, mul_u24(p0 & 0xFF, a0));
+                    const uint32_t h1 = mad_u24(p1 >> 8, a1, mul_u24(p0 >> 8, a0));
+                    const uint32_t v = (((mul_u24(b0, h0 >> 4) >> 16) + (mul_u24(b1, h1 >> 4) >> 16) + 2) >> 2) & 0xFF;
+                    best = max(best, v);
+                }
+                packed |= best << (8 * k);
+            }
+        }
+        const uint32_t fsz = (uint32_t)p.oh * p.ow;
+        uint8_t *env = p.ring + (size_t)n * p.fs * fsz;
+        const uint32_t off = mad_u24((uint32_t)dy, (uint32_t)p.ow, (uint32_t)xq * 4);
+        *reinterpret_cast<uint32_t *>(env + (slot * fsz + off)) = packed;
+        if (clear)
+            for (int s = 0; s < p.fs - 1; ++s) *reinterpret_cast<uint32_t *>(env + (s * fsz + off)) = 0u;
+    }
+    AGX_STAMP(4);
+}
+
+// ---------------------------------------------------------------------------------------------
+// K1, pipelined form: grid = (P, N), block = 256.  Workgroup (part, n) walks bands part, part+P, ...
+// of env n.  The NEXT band's source pieces are requested (registers B) before the current band's
+// luminance (registers A) is computed, so every wave has loads in flight for its whole life instead
+// of once per workgroup; gray bytes are double-buffered in LDS, one barrier per band.  All loads
+// are unconditional: the prefetch past the last band re-reads the last band (L2 hits, never used).
+// ---------------------------------------------------------------------------------------------
+template <int T>
+__global__ __launch_bounds__(T) void k_ingest_pipe(IngestParams p) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int n = blockIdx.y;
+    const int part = blockIdx.x, P = gridDim.x;
+    const int tid = threadIdx.x;
+    const uint32_t cmd = uniform_load_u8(p.cmd + n);
+    const int head = uniform_load_i32(p.head_in + n);
+    const bool skip = (cmd & AGX_CMD_SKIP) != 0;
+    const bool clear = (cmd & AGX_CMD_CLEAR) != 0;
+    if (part == 0 && tid == 0) p.head_out[n] = skip ? head : (clear ? 0 : (head + 1 == p.fs ? 0 : head + 1));
+    if (skip) return;
+    int nvalid = cmd & AGX_CMD_NVALID_MASK;
+    if (nvalid > 2) nvalid = 2;
+    const int slot = clear ? p.fs - 1 : head;
+
+    constexpr int G4 = kRawW / 4, RG = T / G4, kIter = 4;
+    const int BR = p.band_rows;
+    const int gray_bytes = 2 * BR * kRawW * 2;
+    int4 *ytab_s = reinterpret_cast<int4 *>(smem);                        // [oh]  {y0, y1, b0, b1}
+    int2 *xtab_s = reinterpret_cast<int2 *>(smem + sizeof(int4) * p.oh);    // [ow]
+    unsigned char *gray0 = smem + sizeof(int4) * p.oh + sizeof(int2) * p.ow;
+    unsigned char *gray1 = gray0 + gray_bytes;
+    for (int i = tid; i < p.oh; i += T) ytab_s[i] = p.ytab[i];
+    for (int i = tid; i < p.ow; i += T) xtab_s[i] = p.xtab[i];
+    const int ow4 = p.ow >> 2;
+    const int rg = tid / G4, g4 = tid - rg * G4;
+    const bool loader = rg < RG;
+    const uint8_t *fbase = p.frames + (size_t)n * 2 * kRawFrameBytes;
+    const uint32_t col = g4 * 12;
+    const size_t fsz = (size_t)p.oh * p.ow;
+    uint8_t *env = p.ring + (size_t)n * p.fs * fsz;
+    const int last_band = p.nbands - 1;
+    __syncthreads();
+
+    auto offsets = [&](int band, int it, uint32_t &o0, uint32_t &o1, int &d) {
+        const int dy0 = band * BR;
+        const int rows = min(BR, p.oh - dy0);
+        const int nrj = max(nvalid, 1) * rows;
+        const int rj_raw = rg + RG * it;
+        const int rj = min(rj_raw, nrj - 1);
+        const int f = rj >= rows ? 1 : 0;
+        const int dyl = rj - f * rows;
+        const int4 yt = ytab_s[dy0 + dyl];
+        const uint32_t fo = f * kRawFrameBytes + col;
+        o0 = mad_u24((uint32_t)yt.x, kRawRowBytes, fo);
+        o1 = mad_u24((uint32_t)yt.y, kRawRowBytes, fo);
+        d = (rj_raw < nvalid * rows && loader) ? ((f * BR + dyl) * kRawW + g4 * 4) * 2 : -1;
+    };
+    auto issue = [&](U3 (&w0)[kIter], U3 (&w1)[kIter], int band) {
+#pragma unroll
+        for (int it = 0; it < kIter; ++it) {
+            uint32_t o0, o1;
+            int d;
+            offsets(band, it, o0, o1, d);
+            w0[it] = *reinterpret_cast<const U3 *>(fbase + o0);
+            w1[it] = *reinterpret_cast<const U3 *>(fbase + o1);
+        }
+    };
+    auto lum_to_lds = [&](const U3 (&w0)[kIter], const U3 (&w1)[kIter], int band, unsigned char *gray) {
+        uint32_t tie_its = 0;
+#pragma unroll
+        for (int it = 0; it < kIter; ++it) {
+            bool tie = false;
+            const uint32_t top = lum4(w0[it].x, w0[it].y, w0[it].z, tie);
+            const uint32_t bot = lum4(w1[it].x, w1[it].y, w1[it].z, tie);
+            uint32_t o0, o1;
+            int d;
+            offsets(band, it, o0, o1, d);
+            if (d >= 0) {
+                uint2 v;
+                v.x = __builtin_amdgcn_perm(bot, top, 0x05010400u);
+                v.y = __builtin_amdgcn_perm(bot, top, 0x07030602u);
+                *reinterpret_cast<uint2 *>(gray + d) = v;
+                tie_its |= tie ? (1u << it) : 0u;
+            }
+        }
+        if (__builtin_expect(tie_its != 0, 0)) {
+#pragma nounroll
+            for (int it = 0; it < kIter; ++it) {
+                if (!((tie_its >> it) & 1u)) continue;
+                uint32_t o0, o1;
+                int d;
+                offsets(band, it, o0, o1, d);
+                const U3 a = *reinterpret_cast<const U3 *>(fbase + o0);
+                const U3 b = *reinterpret_cast<const U3 *>(fbase + o1);
+#pragma nounroll
+                for (int j = 0; j < 8; ++j) {
+                    const bool which = j & 1;
+                    const int k = j >> 1;
+                    const uint32_t x = which ? b.x : a.x, y = which ? b.y : a.y, z = which ? b.z : a.z;
+                    const uint64_t lo = (uint64_t)x | ((uint64_t)y << 32);
+                    const uint64_t hi = (uint64_t)y | ((uint64_t)z << 32);
+                    const uint32_t px = (uint32_t)(k < 2 ? (lo >> (24 * k)) : (hi >> (24 * k - 32)));
+                    gray[d + j] = (unsigned char)ale_lum_exact(px & 0xFF, (px >> 8) & 0xFF, (px >> 16) & 0xFF);
+                }
+            }
+        }
+    };
+    auto finish = [&](int band, const unsigned char *gray) {
+        const int dy0 = band * BR;
+        const int rows = min(BR, p.oh - dy0);
+        if (tid < rows * ow4) {
+            const int dyl = tid / ow4, xq = tid - dyl * ow4;
+            uint32_t packed = 0;
+            if (nvalid) {
+                const int4 yt = ytab_s[dy0 + dyl];
+                const int b0 = yt.z, b1 = yt.w;
+                const int4 xt01 = *reinterpret_cast<const int4 *>(xtab_s + xq * 4);
+                const int4 xt23 = *reinterpret_cast<const int4 *>(xtab_s + xq * 4 + 2);
+                const int xi[4] = {xt01.x, xt01.z, xt23.x, xt23.z};
+                const int xa[4] = {xt01.y, xt01.w, xt23.y, xt23.w};
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const int x0 = xi[k] & 0xFFFF, x1 = xi[k] >> 16;
+                    const int a0 = xa[k] & 0xFFFF, a1 = xa[k] >> 16;
+                    int best = 0;
+                    for (int f = 0; f < nvalid; ++f) {
+                        const uint16_t *row = reinterpret_cast<const uint16_t *>(gray + (size_t)(f * BR + dyl) * kRawW * 2);
+                        const uint32_t p0 = row[x0], p1 = row[x1];
+                        const uint32_t h0 = mad_u24(p1 & 0xFF, a1, mul_u24(p0 & 0xFF, a0));
+                        const uint32_t h1 = mad_u24(p1 >> 8, a1, mul_u24(p0 >> 8, a0));
+                        const int v = (int)((((mul_u24(b0, h0 >> 4) >> 16) + (mul_u24(b1, h1 >> 4) >> 16) + 2) >> 2) & 0xFF);
+                        best = max(best, v);
+                    }
+                    packed |= (uint32_t)best << (8 * k);
+                }
+            }
+            const size_t off = (size_t)(dy0 + dyl) * p.ow + xq * 4;
+            *reinterpret_cast<uint32_t *>(env + slot * fsz + off) = packed;
+            if (clear)
+                for (int s = 0; s < p.fs - 1; ++s) *reinterpret_cast<uint32_t *>(env + s * fsz + off) = 0u;
+        }
+    };
+
+    U3 a0[kIter], a1[kIter], b0[kIter], b1[kIter];
+    int band = part;
+    if (band > last_band) return;
+    issue(a0, a1, band);
+    while (true) {
+        issue(b0, b1, min(band + P, last_band));
+        lum_to_lds(a0, a1, band, gray0);
+        __syncthreads();
+        finish(band, gray0);
+        band += P;
+        if (band > last_band) break;
+        issue(a0, a1, min(band + P, last_band));
+        lum_to_lds(b0, b1, band, gray1);
+        __syncthreads();
+        finish(band, gray1);
+        band += P;
+        if (band > last_band) break;
+    }
+}
+
+struct IngestGrayParams {
+    const uint8_t *small;    // [N][2][oh][ow]
+    const uint8_t *cmd;
+    uint8_t *ring;
+    const int32_t *head_in;
+    int32_t *head_out;
+    int32_t oh, ow, fs;
+};
+
+// grid = (ceil(oh*ow/4 / 256), N)
+__global__ __launch_bounds__(kThreads) void k_ingest_gray(IngestGrayParams p) {
+    const int n = blockIdx.y;
+    const uint32_t cmd = p.cmd[n];
+    const int head = p.head_in[n];
+    const bool skip = (cmd & AGX_CMD_SKIP) != 0;
+    const bool clear = (cmd & AGX_CMD_CLEAR) != 0;
+    if (blockIdx.x == 0 && threadIdx.x == 0)
+        p.head_out[n] = skip ? head : (clear ? 0 : (head + 1 == p.fs ? 0 : head + 1));
+    if (skip) return;
+    int nvalid = cmd & AGX_CMD_NVALID_MASK;
+    if (nvalid > 2) nvalid = 2;
+    const int slot = clear ? p.fs - 1 : head;
+    const int words = (p.oh * p.ow) >> 2;
+    const int i = blockIdx.x * kThreads + threadIdx.x;
+    if (i >= words) return;
+    const uint32_t *src = reinterpret_cast<const uint32_t *>(p.small) + (size_t)n * 2 * words;
+    uint32_t v = 0;
+    if (nvalid >= 1) v = src[i];
+    if (nvalid >= 2) {
+        const uint32_t u = src[words + i];
+        uint32_t m = 0;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) m |= max((v >> (8 * k)) & 0xFF, (u >> (8 * k)) & 0xFF) << (8 * k);
+        v = m;
+    }
+    uint32_t *env = reinterpret_cast<uint32_t *>(p.ring) + (size_t)n * p.fs * words;
+    env[(size_t)slot * words + i] = v;
+    if (clear)
+        for (int s = 0; s < p.fs - 1; ++s) env[(size_t)s * words + i] = 0u;
+}
+
+// K1b (DMC pixel front end, reference dmc_env.py:175-186): frames are obs-sized RGB renders
+// u8[N][oh][ow][3]; gray = cv2.cvtColor(obs, COLOR_BGR2GRAY) - OpenCV's fixed-point weights with channel 0
+// taken as blue, exactly what the reference does to an RGB render - appended to the ring, no max-pool, no
+// resize.  One thread = 4 output pixels = 12 source bytes (three dwords, lane-contiguous).
+struct IngestRgbParams {
+    const uint8_t *frames;   // [N][oh][ow][3]
+    const uint8_t *cmd;      // [N]
+    uint8_t *ring;
+    const int32_t *head_in;
+    int32_t *head_out;
+    int32_t oh, ow, fs;
+    uint32_t k0, k1, k2;     // weights of channels 0,1,2; k0 + k1 + k2 == 1 << shift
+    uint32_t shift;
+};
+
+// grid = (ceil(oh*ow/4 / 256), N)
+__global__ __launch_bounds__(kThreads) void k_ingest_rgb(IngestRgbParams p) {
+    const int n = blockIdx.y;
+    const int words = (p.oh * p.ow) >> 2;
+    const int i = min((int)(blockIdx.x * kThreads + threadIdx.x), words - 1);
+    // the pixel loads go out before the per-env command / head loads they do not depend on
+    const uint32_t *src = reinterpret_cast<const uint32_t *>(p.frames) + ((size_t)n * words + i) * 3;
+    const uint32_t a = src[0], b = src[1], c = src[2];
+    const uint32_t cmd = p.cmd[n];
+    const int head = p.head_in[n];
+    const bool skip = (cmd & AGX_CMD_SKIP) != 0;
+    const bool clear = (cmd & AGX_CMD_CLEAR) != 0;
+    if (blockIdx.x == 0 && threadIdx.x == 0)
+        p.head_out[n] = skip ? head : (clear ? 0 : (head + 1 == p.fs ? 0 : head + 1));
+    if (skip || (int)(blockIdx.x * kThreads + threadIdx.x) >= words) return;
+    const uint32_t rnd = 1u << (p.shift - 1);
+    auto g = [&](uint32_t c0, uint32_t c1, uint32_t c2) {
+        return (mad_u24(c0, p.k0, mad_u24(c1, p.k1, mad_u24(c2, p.k2, rnd))) >> p.shift) & 0xFFu;
+    };
+    // bytes: a = c0 c1 c2 c0' | b = c1' c2' c0" c1" | c = c2" c0"' c1"' c2"'
+    uint32_t v = 0;
+    if ((cmd & AGX_CMD_NVALID_MASK) != 0) {
+        v = g(a & 0xFF, (a >> 8) & 0xFF, (a >> 16) & 0xFF);
+        v |= g(a >> 24, b & 0xFF, (b >> 8) & 0xFF) << 8;
+        v |= g((b >> 16) & 0xFF, b >> 24, c & 0xFF) << 16;
+        v |= g((c >> 8) & 0xFF, (c >> 16) & 0xFF, c >> 24) << 24;
+    }
+    const int slot = clear ? p.fs - 1 : head;
+    uint32_t *env = reinterpret_cast<uint32_t *>(p.ring) + (size_t)n * p.fs * words;
+    env[(size_t)slot * words + i] = v;
+    if (clear)
+        for (int s = 0; s < p.fs - 1; ++s) env[(size_t)s * words + i] = 0u;
+}
+
+}  // namespace agx

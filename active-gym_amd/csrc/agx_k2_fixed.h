@@ -1,0 +1,324 @@
+// agx_k2_fixed.h - K2: FixedFovealEnv (k_fovea_fixed, the two-slot form, and the fused step launches).
+#pragma once
+#include "agx_fov_common.h"
+#include "agx_k1_ingest.h"
+
+namespace agx {
+
+// ---------------------------------------------------------------------------------------------
+// K2: FixedFovealEnv
+// grid = (fs, N): one workgroup per (env, stacked frame); block = 256
+//   MODE = AGX_OUT_RESIZE: LDS s[fh][fw] -> H[fh][ow] (horizontal lerp) -> float4 rows of the
+//          84x84 output = vertical lerp of two ds_read_b128; every store is 16 B/lane, lane-linear.
+// ---------------------------------------------------------------------------------------------
+template <class T4>
+__device__ __forceinline__ void store_obs(T4 *dst, const T4 &v) {
+#ifndef AGX_K2_PLAIN_STORES
+    // write-once stream: nontemporal, so the next launch (K1) does not queue behind ~115 MB of dirty
+    // L2 / Infinity-Cache lines (measured: K1 is ~6 us faster after nontemporal obs stores)
+    typedef float f4v __attribute__((ext_vector_type(4)));
+    const f4v w = {v.x, v.y, v.z, v.w};
+    __builtin_nontemporal_store(w, reinterpret_cast<f4v *>(dst));
+#else
+    *dst = v;
+#endif
+}
+
+// grid = (fs, N): workgroup (sl, n) owns PHYSICAL ring slot sl of env n, block = 256.
+// Every stage that costs a memory round trip is started at once:
+//   * the whole u8 frame of that slot (address known at launch) -> registers -> LDS,
+//   * the scalar chain action / fov_loc / head -> (r, c) and the stack position j of this slot,
+//   * this thread's column taps (registers) and one row-tap entry (-> LDS).
+// u8 -> float32 k/255 goes through a 256-entry LDS table (one exact division per thread).
+//   RESIZE: H[fh][ow] = horizontal lerp of the window rows (thread = fixed column x, rows y = yb+3k),
+//           then each output float4 is the vertical lerp of two ds_read_b128; stores are 16 B per
+//           lane, lane-linear, 1 KiB per wave at 1-KiB steps, nontemporal.
+// (ablation of the previous serial version at N=1024: loc chain 5.8 us, loc-dependent window load
+//  6.3 us, H pass with a tap load per iteration 7.3 us, row-tap loads 2.1 us of a 32.7 us launch.)
+template <class G, int MODE>
+__device__ __forceinline__ void fovea_fixed_body(const G g, const FovParams &p, const int sl, const int n,
+                                                 unsigned char *smem) {
+    const int tid = threadIdx.x;
+    constexpr int T = kThreads;
+    (void)T;
+    AGX_STAMP(0);
+    const int oh = g.oh(), ow = g.ow(), fh = g.fh(), fw = g.fw();
+    if (p.mask && !p.mask[n]) {
+        if (sl == 0 && tid < 2) p.loc_out[2 * n + tid] = p.loc_in[2 * n + tid];
+        return;
+    }
+    int head_fixup = 0;                      // what to add to p.head[n] to get the post-ingest head
+    if (p.phase != 0) {
+        const uint32_t cmd = uniform_load_u8(p.cmd + n);
+        const bool skip = (cmd & AGX_CMD_SKIP) != 0, clear = (cmd & AGX_CMD_CLEAR) != 0 && !skip;
+        const int h = uniform_load_i32(p.head + n);
+        // slot the ingest writes: the pre-ingest head (fs-1 after a clear, which also zeroes the others)
+        int wslot;
+        if (p.phase == 1) {
+            wslot = h;
+            head_fixup = skip ? 0 : (clear ? -h : (h + 1 == p.fs ? 1 - p.fs : 1));
+        } else {
+            wslot = skip ? h : (h == 0 ? p.fs - 1 : h - 1);
+        }
+        const bool touched = clear || sl == wslot;
+        if ((p.phase == 1) == touched) return;            // phase 1 takes the untouched slots, phase 2 the rest
+    }
+    // LDS carve: lut[256] | raw[oh*ow] u8 | ytab[oh] | H[fh][ow]
+    float *lut = reinterpret_cast<float *>(smem);
+    unsigned char *raw = smem + 1024;
+    const int fbytes = oh * ow;                                       // multiple of 4 (ow % 4 == 0)
+    const int raw_pad = (fbytes + 15) & ~15;
+    Tap *ytab_s = reinterpret_cast<Tap *>(raw + raw_pad);
+    float *H = reinterpret_cast<float *>(ytab_s + oh);
+
+    // ---- every round trip starts now: the frame, the taps, then the small state loads.  (The first
+    // use of the state waits for everything older too, which is fine: all of it is needed before the
+    // LDS image can be written; what matters is that nothing waits before everything is issued.)
+    const uint32_t *fsrc = reinterpret_cast<const uint32_t *>(p.ring + ((size_t)n * p.fs + sl) * (size_t)fbytes);
+    const int fwords = fbytes >> 2;
+    constexpr int kFW = 7;                                            // 7 * 256 dwords cover 84x84; loop beyond
+    uint32_t fw_[kFW];
+#pragma unroll
+    for (int k = 0; k < kFW; ++k) fw_[k] = fsrc[min(tid + k * kThreads, fwords - 1)];
+    const int xcol = tid % ow, yb = tid / ow;                         // phase-C column / first row
+    int4 xt = make_int4(0, 0, 0, 0), yt = xt;                         // raw Tap bits {lo, aux, a, b}
+    if (MODE == AGX_OUT_RESIZE) {
+        xt = *reinterpret_cast<const int4 *>(p.xtab + xcol);
+        yt = *reinterpret_cast<const int4 *>(p.ytab + min(tid, oh - 1));
+    }
+    const LocIn lin = load_loc_inputs(p, n);
+    const int head = p.head[n] + head_fixup;
+    lut[tid] = unit((uint32_t)tid);
+    int r, c;
+    compute_loc(p, lin, oh - fh, ow - fw, r, c);
+    int j = sl - head;                                                // stack position of this slot
+    if (j < 0) j += p.fs;
+    if (sl == 0 && tid == 0) {
+        p.loc_out[2 * n] = r;
+        p.loc_out[2 * n + 1] = c;
+        if (p.user_loc) {
+            p.user_loc[2 * n] = r;
+            p.user_loc[2 * n + 1] = c;
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < kFW; ++k)
+        if (tid + k * kThreads < fwords) reinterpret_cast<uint32_t *>(raw)[tid + k * kThreads] = fw_[k];
+    for (int i = tid + kFW * kThreads; i < fwords; i += kThreads) reinterpret_cast<uint32_t *>(raw)[i] = fsrc[i];
+    if (MODE == AGX_OUT_RESIZE) {
+        if (tid < oh) *reinterpret_cast<int4 *>(ytab_s + tid) = yt;
+        for (int i = tid + kThreads; i < oh; i += kThreads) ytab_s[i] = p.ytab[i];
+    }
+    AGX_STAMP(1);
+    __syncthreads();
+    AGX_STAMP(2);
+
+    const unsigned char *win = raw + r * ow + c;                      // window origin inside the frame
+    if (MODE == AGX_OUT_RAW) {
+        float *out = p.obs + ((size_t)n * p.fs + j) * (size_t)(fh * fw);
+        for (int i = tid; i < fh * fw; i += kThreads) {
+            const int y = i / fw, x = i - y * fw;
+            out[i] = lut[win[y * ow + x]];
+        }
+        return;
+    }
+    const int ow4 = ow >> 2;
+    float4 *out4 = reinterpret_cast<float4 *>(p.obs) + ((size_t)n * p.fs + j) * (size_t)(oh * ow4);
+    if (MODE == AGX_OUT_MASK) {
+        for (int q = tid; q < oh * ow4; q += kThreads) {
+            const int row = q / ow4, x = (q - row * ow4) * 4;
+            float v[4] = {0.f, 0.f, 0.f, 0.f};
+            if (row >= r && row < r + fh && x + 3 >= c && x < c + fw) {
+                const uint32_t w = *reinterpret_cast<const uint32_t *>(raw + row * ow + x);
+#pragma unroll
+                for (int k = 0; k < 4; ++k)
+                    if (x + k >= c && x + k < c + fw) v[k] = lut[(w >> (8 * k)) & 0xFF];
+            }
+            store_obs(&out4[q], make_float4(v[0], v[1], v[2], v[3]));
+        }
+        return;
+    }
+    // ---- RESIZE, phase C: thread owns column xcol (taps in registers), rows yb, yb + rstep, ...
+    const int rstep = kThreads / ow;                                  // 3 for ow = 84
+    if (rstep > 0) {
+        if (yb < rstep) {
+            const unsigned char *c0 = win + xt.x, *c1 = win + xt.y;
+            const float wa = __int_as_float(xt.z), wb = __int_as_float(xt.w);
+#pragma unroll 10
+            for (int y = yb; y < fh; y += rstep)
+                H[y * ow + xcol] = wa * lut[c0[y * ow]] + wb * lut[c1[y * ow]];
+        }
+    } else {                                                          // ow > 256: generic striding
+        for (int i = tid; i < fh * ow; i += kThreads) {
+            const int y = i / ow, x = i - y * ow;
+            const Tap t = p.xtab[x];
+            H[i] = t.a * lut[win[y * ow + t.lo]] + t.b * lut[win[y * ow + t.aux]];
+        }
+    }
+    __syncthreads();
+    AGX_STAMP(3);
+    // ---- phase D
+    const float4 *H4 = reinterpret_cast<const float4 *>(H);
+#pragma unroll 7
+    for (int q = tid; q < oh * ow4; q += kThreads) {
+        const int row = q / ow4, x4 = q - row * ow4;
+        const Tap t = ytab_s[row];
+        const float4 a = H4[t.lo * ow4 + x4];
+        const float4 b = H4[t.aux * ow4 + x4];
+        float4 o;
+        o.x = t.a * a.x + t.b * b.x;
+        o.y = t.a * a.y + t.b * b.y;
+        o.z = t.a * a.z + t.b * b.z;
+        o.w = t.a * a.w + t.b * b.w;
+        store_obs(&out4[q], o);
+    }
+    AGX_STAMP(4);
+}
+
+template <class G, int MODE>
+__global__ __launch_bounds__(kThreads) void k_fovea_fixed(G g, FovParams p) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    fovea_fixed_body<G, MODE>(g, p, blockIdx.x, blockIdx.y, smem);
+}
+
+// ---------------------------------------------------------------------------------------------
+// K2, two slots per workgroup (resize_to_full, stand-alone launch): grid = (fs/2, N), block = 256.
+// The occupancy timeline of the one-slot form shows two synchronized rounds of workgroups, each wave
+// spending 54 % of its life on the load chain.  Here a workgroup requests BOTH of its frames up front
+// and keeps the second in registers while the first goes LDS -> H -> stores, so the second frame's load
+// latency is hidden and the whole launch is resident at once (2048 workgroups x 4 waves at N=1024).
+// ---------------------------------------------------------------------------------------------
+template <class G>
+__global__ __launch_bounds__(kThreads) void k_fovea_fixed2(G g, FovParams p) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int n = blockIdx.y, tid = threadIdx.x;
+    const int oh = g.oh(), ow = g.ow(), fh = g.fh(), fw = g.fw();
+    const int sl0 = 2 * blockIdx.x;
+    if (p.mask && !p.mask[n]) {
+        if (sl0 == 0 && tid < 2) p.loc_out[2 * n + tid] = p.loc_in[2 * n + tid];
+        return;
+    }
+    float *lut = reinterpret_cast<float *>(smem);
+    unsigned char *raw = smem + 1024;
+    const int fbytes = oh * ow, fwords = fbytes >> 2;
+    const int raw_pad = (fbytes + 15) & ~15;
+    Tap *ytab_s = reinterpret_cast<Tap *>(raw + raw_pad);
+    float *H = reinterpret_cast<float *>(ytab_s + oh);
+    constexpr int kFW = 7;
+    uint32_t fa[kFW], fb[kFW];
+    const uint32_t *src0 = reinterpret_cast<const uint32_t *>(p.ring + ((size_t)n * p.fs + sl0) * (size_t)fbytes);
+    const uint32_t *src1 = src0 + fwords;
+#pragma unroll
+    for (int k = 0; k < kFW; ++k) fa[k] = src0[min(tid + k * kThreads, fwords - 1)];
+#pragma unroll
+    for (int k = 0; k < kFW; ++k) fb[k] = src1[min(tid + k * kThreads, fwords - 1)];
+    const int xcol = tid % ow, yb = tid / ow;
+    const int4 xt = *reinterpret_cast<const int4 *>(p.xtab + xcol);
+    const int4 yt = *reinterpret_cast<const int4 *>(p.ytab + min(tid, oh - 1));
+    const LocIn lin = load_loc_inputs(p, n);
+    const int head = p.head[n];
+    lut[tid] = unit((uint32_t)tid);
+    int r, c;
+    compute_loc(p, lin, oh - fh, ow - fw, r, c);
+    if (sl0 == 0 && tid == 0) {
+        p.loc_out[2 * n] = r;
+        p.loc_out[2 * n + 1] = c;
+        if (p.user_loc) {
+            p.user_loc[2 * n] = r;
+            p.user_loc[2 * n + 1] = c;
+        }
+    }
+    if (tid < oh) *reinterpret_cast<int4 *>(ytab_s + tid) = yt;
+    for (int i = tid + kThreads; i < oh; i += kThreads) ytab_s[i] = p.ytab[i];
+    const int ow4 = ow >> 2;
+    const int rstep = kThreads / ow;
+    const float wa = __int_as_float(xt.z), wb = __int_as_float(xt.w);
+    const float4 *H4 = reinterpret_cast<const float4 *>(H);
+#pragma unroll
+    for (int half = 0; half < 2; ++half) {
+        if (half) __syncthreads();                                    // raw / H of the first frame are consumed
+#pragma unroll
+        for (int k = 0; k < kFW; ++k)
+            if (tid + k * kThreads < fwords) reinterpret_cast<uint32_t *>(raw)[tid + k * kThreads] = half ? fb[k] : fa[k];
+        if (kFW * kThreads < fwords) {
+            const uint32_t *src = half ? src1 : src0;
+            for (int i = tid + kFW * kThreads; i < fwords; i += kThreads) reinterpret_cast<uint32_t *>(raw)[i] = src[i];
+        }
+        __syncthreads();
+        const unsigned char *win = raw + r * ow + c;
+        if (rstep > 0) {
+            if (yb < rstep) {
+                const unsigned char *c0 = win + xt.x, *c1 = win + xt.y;
+#pragma unroll 10
+                for (int y = yb; y < fh; y += rstep) H[y * ow + xcol] = wa * lut[c0[y * ow]] + wb * lut[c1[y * ow]];
+            }
+        } else {
+            for (int i = tid; i < fh * ow; i += kThreads) {
+                const int y = i / ow, x = i - y * ow;
+                const Tap t = p.xtab[x];
+                H[i] = t.a * lut[win[y * ow + t.lo]] + t.b * lut[win[y * ow + t.aux]];
+            }
+        }
+        __syncthreads();
+        int j = sl0 + half - head;
+        if (j < 0) j += p.fs;
+        float4 *out4 = reinterpret_cast<float4 *>(p.obs) + ((size_t)n * p.fs + j) * (size_t)(oh * ow4);
+#pragma unroll 7
+        for (int q = tid; q < oh * ow4; q += kThreads) {
+            const int row = q / ow4, x4 = q - row * ow4;
+            const Tap t = ytab_s[row];
+            const float4 a = H4[t.lo * ow4 + x4];
+            const float4 b = H4[t.aux * ow4 + x4];
+            float4 o;
+            o.x = t.a * a.x + t.b * b.x;
+            o.y = t.a * a.y + t.b * b.y;
+            o.z = t.a * a.z + t.b * b.z;
+            o.w = t.a * a.w + t.b * b.w;
+            store_obs(&out4[q], o);
+        }
+    }
+}
+
+// Fused step, second launch: grid = (1, N).  One workgroup per env processes the ring slot the ingest
+// has just written; for the rare cleared env (full reset: every slot changed) it walks all of them.
+template <class G>
+__global__ __launch_bounds__(kThreads) void k_step_fixed_tail(G g, FovParams p) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int n = blockIdx.y;
+    if (p.mask && !p.mask[n]) return;        // (the fused step never passes a mask; kept for symmetry)
+    const uint32_t cmd = uniform_load_u8(p.cmd + n);
+    const bool skip = (cmd & AGX_CMD_SKIP) != 0, clear = (cmd & AGX_CMD_CLEAR) != 0 && !skip;
+    const int h = uniform_load_i32(p.head + n);
+    const int wslot = skip ? h : (h == 0 ? p.fs - 1 : h - 1);
+    FovParams q = p;
+    q.phase = 0;                             // `head` is already the post-ingest head
+    if (!clear) {
+        fovea_fixed_body<G, AGX_OUT_RESIZE>(g, q, wslot, n, smem);
+        // slot 0 is the one that publishes fov_loc; it ran in the first launch unless it is the written slot
+        return;
+    }
+    for (int sl = 0; sl < p.fs; ++sl) {
+        if (sl) __syncthreads();             // the LDS image of the previous slot has been consumed
+        fovea_fixed_body<G, AGX_OUT_RESIZE>(g, q, sl, n, smem);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Fused step, first launch: grid = (bands + fs, N), block = 256.  Workgroups x < bands ingest band x
+// of env n; workgroups x >= bands run the resize_to_full fovea of ring slot x - bands, but only for
+// the slots this step's ingest does not touch (phase 1).  The two kinds of workgroup are independent
+// (disjoint ring slots, double-buffered head / fov_loc), so the store-bound fovea work fills the
+// issue slots and the drain of the load/ALU-bound ingest (K1 alone: CUs run dry for its last 9 us).
+// The written slot follows in a second, small launch of k_fovea_fixed with phase 2.
+// ---------------------------------------------------------------------------------------------
+template <class G>
+__global__ __launch_bounds__(kThreads) void k_step_fixed(G g, IngestParams pi, FovParams pf) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int x = blockIdx.x, n = blockIdx.y;
+    if (x < pi.nbands)
+        ingest_band<kThreads>(pi, x, n, smem);
+    else
+        fovea_fixed_body<G, AGX_OUT_RESIZE>(g, pf, x - pi.nbands, n, smem);
+}
+
+}  // namespace agx
