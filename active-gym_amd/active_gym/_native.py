@@ -17,7 +17,7 @@ MODE_ABSOLUTE, MODE_RELATIVE = 0, 1
 DT_F32, DT_F64, DT_I32, DT_I64 = 0, 1, 2, 3
 FOV_LOC, FOV_RES = 0, 1
 CMD_CLEAR, CMD_SKIP = 0x04, 0x08
-K_INGEST, K_FOVEA, K_FULL, K_INGEST_RGB = 1, 2, 3, 4
+K_INGEST, K_FOVEA, K_FULL, K_INGEST_RGB, K_INGEST_GRAY_RAW = 1, 2, 3, 4, 5
 GRAY_CV15, GRAY_CV14 = 0, 1
 
 RAW_H, RAW_W = 210, 160
@@ -44,6 +44,7 @@ SIGNATURES = {
     "agx_algorithmic_bytes": (C.c_int64, [_P, C.c_int]),
     "agx_ingest": (C.c_int, [_P, _P, _P, _P]),
     "agx_ingest_gray": (C.c_int, [_P, _P, _P, _P]),
+    "agx_ingest_gray_raw": (C.c_int, [_P, _P, _P, _P]),
     "agx_ingest_rgb": (C.c_int, [_P, _P, _P, C.c_int, _P]),
     "agx_observe_full": (C.c_int, [_P, _P, _P]),
     "agx_get_stack_u8": (C.c_int, [_P, _P, _P]),

@@ -94,6 +94,13 @@ class SyntheticALE:
             s[r:r + 24, c:c + 16] = self._palette[2 + k]
         return s
 
+    def getScreenGrayscale(self):
+        """(210, 160, 1) u8: ALE's palette luminance of the RGB screen, round(.2989 r + .5870 g + .1140 b)."""
+        rgb = self.getScreenRGB().astype(np.float64)
+        x = (rgb[..., 0] * 0.2989 + rgb[..., 1] * 0.5870) + rgb[..., 2] * 0.1140
+        fl = np.floor(x)
+        return (fl + ((x - fl) >= 0.5)).astype(np.uint8)[..., None]
+
 
 def _make_ale(args, index):
     """Real ALE, configured as reference atari_env.py:44-50."""

@@ -23,7 +23,8 @@ class AgxrConfig(C.Structure):
                 ("action_repeat", C.c_int32), ("clip_reward", C.c_int32), ("num_threads", C.c_int32),
                 ("seed", C.c_int64), ("max_episode_frames", C.c_int32), ("scripted_actions", C.c_int32),
                 ("scripted_lives", C.c_int32), ("scripted_p_life", C.c_int32), ("scripted_p_over", C.c_int32),
-                ("backend", C.c_char_p), ("ale_lib", C.c_char_p), ("rom_path", C.c_char_p)]
+                ("backend", C.c_char_p), ("ale_lib", C.c_char_p), ("rom_path", C.c_char_p),
+                ("gray_frames", C.c_int32), ("reserved", C.c_int32)]
 
 
 _P = C.c_void_p
@@ -87,6 +88,8 @@ class NativeHostRunner:
         cfg.scripted_lives = int(getattr(args, "scripted_lives", 3))
         cfg.scripted_p_life = int(getattr(args, "scripted_p_life", 4))
         cfg.scripted_p_over = int(getattr(args, "scripted_p_over", 1))
+        self.gray = getattr(args, "frame_format", "rgb") == "gray"
+        cfg.gray_frames = int(self.gray)
         cfg.backend = backend.encode()
         if backend == "ale_c":
             so, atari_py = _find_libale_c()
@@ -99,9 +102,10 @@ class NativeHostRunner:
             raise RuntimeError("agxr_create: " + (self._lib.agxr_last_error(None) or b"").decode())
         self.num_actions = self._lib.agxr_num_actions(self._h)
         self.actions = [list(range(self.num_actions))] * self.num_envs
+        shape = (self.num_envs, 2, RAW_H, RAW_W) + (() if self.gray else (3,))
         if frames is None:
-            frames = np.zeros((self.num_envs, 2, RAW_H, RAW_W, 3), np.uint8)
-        assert frames.shape == (self.num_envs, 2, RAW_H, RAW_W, 3) and frames.dtype == np.uint8 and frames.flags.c_contiguous
+            frames = np.zeros(shape, np.uint8)
+        assert frames.shape == shape and frames.dtype == np.uint8 and frames.flags.c_contiguous
         self.frames = frames
         self.training = True
         self._motor = np.zeros(self.num_envs, np.int32)

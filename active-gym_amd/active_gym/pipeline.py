@@ -124,7 +124,8 @@ class ObsPipeline:
         return C.c_void_p(t.data_ptr())
 
     def algorithmic_bytes(self, kernel: str) -> int:
-        k = {"ingest": nat.K_INGEST, "fovea": nat.K_FOVEA, "full": nat.K_FULL, "ingest_rgb": nat.K_INGEST_RGB}[kernel]
+        k = {"ingest": nat.K_INGEST, "fovea": nat.K_FOVEA, "full": nat.K_FULL, "ingest_rgb": nat.K_INGEST_RGB,
+             "ingest_gray_raw": nat.K_INGEST_GRAY_RAW}[kernel]
         v = self._lib.agx_algorithmic_bytes(self._ctx, k)
         if v < 0:
             raise nat.AgxError(int(v), "algorithmic_bytes")
@@ -136,6 +137,12 @@ class ObsPipeline:
         pf = self._chk(frames, (self.num_envs, 2, nat.RAW_H, nat.RAW_W, 3), torch.uint8, "frames")
         pc = self._chk(cmd, (self.num_envs,), torch.uint8, "cmd")
         nat.check(self._lib.agx_ingest(self._ctx, pf, pc, self._stream()), self._ctx)
+
+    def ingest_gray_raw(self, gray: torch.Tensor, cmd: torch.Tensor):
+        """gray u8[N,2,210,160]: ALE's own grayscale screens (what the reference reads, atari_env.py:74)."""
+        pg = self._chk(gray, (self.num_envs, 2, nat.RAW_H, nat.RAW_W), torch.uint8, "gray")
+        pc = self._chk(cmd, (self.num_envs,), torch.uint8, "cmd")
+        nat.check(self._lib.agx_ingest_gray_raw(self._ctx, pg, pc, self._stream()), self._ctx)
 
     def ingest_gray(self, small: torch.Tensor, cmd: torch.Tensor):
         """small u8[N,2,obs_h,obs_w] already obs-sized gray frames."""

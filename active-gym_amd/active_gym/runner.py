@@ -45,9 +45,13 @@ class AtariHostRunner:
         self.num_actions = len(acts[0])
         self.lives = np.zeros(self.num_envs, np.int64)
         self.life_termination = np.zeros(self.num_envs, bool)
+        # frame_format "gray": ALE's own grayscale screens (getScreenGrayscale - what the reference reads,
+        # atari_env.py:74) instead of RGB; a third of the bytes, no luminance arithmetic on the device
+        self.gray = getattr(args, "frame_format", "rgb") == "gray"
+        shape = (self.num_envs, 2, RAW_H, RAW_W) + (() if self.gray else (3,))
         if frames is None:
-            frames = np.zeros((self.num_envs, 2, RAW_H, RAW_W, 3), np.uint8)
-        assert frames.shape == (self.num_envs, 2, RAW_H, RAW_W, 3) and frames.dtype == np.uint8
+            frames = np.zeros(shape, np.uint8)
+        assert frames.shape == shape and frames.dtype == np.uint8
         self.frames = frames
         n_workers = workers if workers is not None else min(self.num_envs, os.cpu_count() or 1)
         self._pool = ThreadPoolExecutor(max_workers=n_workers) if n_workers > 1 else None
@@ -67,7 +71,11 @@ class AtariHostRunner:
 
     def _grab(self, i, slot, buf=None):
         e = self.emulators[i]
-        np.copyto((self.frames if buf is None else buf)[i, slot], e.getScreenRGB())
+        dst = (self.frames if buf is None else buf)[i, slot]
+        if self.gray:
+            np.copyto(dst, np.asarray(e.getScreenGrayscale()).reshape(RAW_H, RAW_W))
+        else:
+            np.copyto(dst, e.getScreenRGB())
 
     def _map(self, fn, idx: Sequence[int]):
         idx = list(idx)

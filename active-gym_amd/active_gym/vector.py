@@ -128,19 +128,27 @@ class AtariVecEnv:
         return Discrete(self.runner.num_actions)
 
     def _ingest(self):
-        self.pipe.ingest(self._d_frames, self._d_cmd)
+        if self._gray:
+            self.pipe.ingest_gray_raw(self._d_frames, self._d_cmd)
+        else:
+            self.pipe.ingest(self._d_frames, self._d_cmd)
 
     def _extra_info(self, info):
         return info
 
     def _setup_source(self, args, noop_fn, env_offset):
         # host side: pinned staging for step frames and for reset frames, device twins
-        shape = (self.num_envs, 2, nat.RAW_H, nat.RAW_W, 3)
+        fmt = getattr(args, "frame_format", "rgb")
+        if fmt not in ("rgb", "gray"):
+            raise ValueError("frame_format must be 'rgb' (getScreenRGB, luminance on the device) or 'gray' (getScreenGrayscale)")
+        self._gray = fmt == "gray"
+        px = () if self._gray else (3,)
+        shape = (self.num_envs, 2, nat.RAW_H, nat.RAW_W) + px
         self._h_frames = torch.empty(shape, dtype=torch.uint8, pin_memory=True)
         self._d_frames = torch.empty(shape, dtype=torch.uint8, device=self.device)
         # reset screens get their own pinned buffer: the autoreset inside step() must not overwrite step
         # screens whose asynchronous H2D copy may still be in flight
-        self._h_rframes = torch.empty((self.num_envs, 1, nat.RAW_H, nat.RAW_W, 3), dtype=torch.uint8, pin_memory=True)
+        self._h_rframes = torch.empty((self.num_envs, 1, nat.RAW_H, nat.RAW_W) + px, dtype=torch.uint8, pin_memory=True)
         self._h_rcmd = torch.empty((self.num_envs,), dtype=torch.uint8, pin_memory=True)
         self._ev_copy = torch.cuda.Event()
         self._ev_rcopy = torch.cuda.Event()

@@ -56,7 +56,7 @@ def build_runner(force=False, verbose=False):
     if not force and os.path.exists(RUNNER_OUT) and all(os.path.getmtime(RUNNER_OUT) >= os.path.getmtime(d) for d in deps):
         return RUNNER_OUT
     os.makedirs(OUT_DIR, exist_ok=True)
-    cmd = ["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-fvisibility=hidden", "-Wall", "-I", os.path.join(REPO, "include"),
+    cmd = ["g++", "-O2", "-ffp-contract=off", "-std=c++17", "-fPIC", "-shared", "-fvisibility=hidden", "-Wall", "-I", os.path.join(REPO, "include"),
            RUNNER_SRC, "-o", RUNNER_OUT + ".tmp", "-pthread", "-ldl"]
     if verbose:
         print(" ".join(cmd))

@@ -490,6 +490,8 @@ int64_t agx_algorithmic_bytes(const agx_ctx *ctx, int kernel_id) {
     switch (kernel_id) {
         case AGX_K_INGEST:   // two frames, only the source rows the vertical resize touches + one u8 slot
             return N * (2 * (int64_t)ctx->rows_touched * kRawRowBytes + px);
+        case AGX_K_INGEST_GRAY_RAW:   // two gray frames, only the touched source rows, + one u8 slot
+            return N * (2 * (int64_t)ctx->rows_touched * kRawW + px);
         case AGX_K_INGEST_RGB:   // one obs-sized RGB render in, one u8 slot out
             return N * px * 4;
         case AGX_K_FULL:
@@ -568,6 +570,25 @@ int agx_ingest(agx_ctx *ctx, const uint8_t *d_frames, const uint8_t *d_cmd, void
         hipLaunchKernelGGL(k_ingest<128>, dim3(bands, c.num_envs), dim3(128), lds, S(stream), p);
     else
         hipLaunchKernelGGL(k_ingest<256>, dim3(bands, c.num_envs), dim3(256), lds, S(stream), p);
+    AGX_HIP(ctx, hipGetLastError());
+    ctx->cur_head ^= 1;
+    return AGX_OK;
+}
+
+int agx_ingest_gray_raw(agx_ctx *ctx, const uint8_t *d_gray, const uint8_t *d_cmd, void *stream) {
+    if (!ctx) return AGX_E_INVALID;
+    if (!d_gray || !d_cmd) return fail(ctx, AGX_E_INVALID, "agx_ingest_gray_raw: null buffer");
+    const agx_config &c = ctx->cfg;
+    if (c.obs_h != c.obs_w)
+        return fail(ctx, AGX_E_STATE, "agx_ingest_gray_raw needs a square obs_size (cv2.resize takes (width, height): atari_env.py:74)");
+    DeviceGuard g(c.device);
+    IngestParams p = ingest_params(ctx, d_gray, d_cmd);
+    // always the default 256-thread band form (the opt-in variants are RGB-only)
+    const int br = std::max(1, std::min(2 * (kThreads / 40), kThreads / (c.obs_w / 4)));
+    p.band_rows = std::min(br, ctx->band_rows > 0 && ctx->ingest_t == 256 ? ctx->band_rows : br);
+    p.nbands = (c.obs_h + p.band_rows - 1) / p.band_rows;
+    const size_t lds = sizeof(int4) * p.band_rows + sizeof(int2) * c.obs_w + (size_t)2 * p.band_rows * 2 * kRawW;
+    hipLaunchKernelGGL(k_ingest_grayraw, dim3(p.nbands, c.num_envs), dim3(kThreads), lds, S(stream), p);
     AGX_HIP(ctx, hipGetLastError());
     ctx->cur_head ^= 1;
     return AGX_OK;

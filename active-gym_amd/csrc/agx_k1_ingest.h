@@ -80,10 +80,14 @@ struct IngestParams {
 // LDS gray layout: [frame][dyl][x][2] — the vertical pair (row y0, row y1) of one source column is
 // one aligned u16, so the bilinear taps of an output pixel are two ds_read_u16.
 // Measured floor of this access shape with no arithmetic at all: ~30 us at N=1024 (tools/membench.hip).
-template <int T>
+// GRAY: the source frames are already ALE's own grayscale screens, u8 [N][2][210][160] (`getScreenGrayscale`, what the
+// reference itself reads, atari_env.py:74): one dword = 4 pixels per lane, no luminance arithmetic, a third of the bytes.
+template <int T, bool GRAY = false>
 __device__ __forceinline__ void ingest_band(const IngestParams &p, const int band, const int n, unsigned char *smem) {
     const int tid = threadIdx.x;
     AGX_STAMP(0);
+    constexpr uint32_t kRowB = GRAY ? kRawW : kRawRowBytes;               // source row / frame pitch in bytes
+    constexpr uint32_t kFrameB = kRawH * kRowB;
     const int BR = p.band_rows;
     const int dy0 = band * BR;
     const int rows = min(BR, p.oh - dy0);
@@ -106,8 +110,8 @@ __device__ __forceinline__ void ingest_band(const IngestParams &p, const int ban
     constexpr int RG = T / G4;                                            // row groups: 6 (T=256) / 3 (T=128)
     constexpr int kIter = 4;                                              // 2 frames * band_rows / RG
     const int rg = tid / G4, g4 = tid - rg * G4;
-    const uint8_t *fbase = p.frames + (size_t)n * 2 * kRawFrameBytes;     // wave-uniform base
-    const uint32_t col = g4 * 12;
+    const uint8_t *fbase = p.frames + (size_t)n * 2 * kFrameB;            // wave-uniform base
+    const uint32_t col = g4 * (GRAY ? 4 : 12);
     int nvalid = 2;                                                       // speculative until cmd arrives
     auto row_offsets = [&](int it, uint32_t &o0, uint32_t &o1, int &d) {
         const int nrj = max(nvalid, 1) * rows;
@@ -124,19 +128,24 @@ __device__ __forceinline__ void ingest_band(const IngestParams &p, const int ban
             y0 = yt.x;
             y1 = yt.y;
         }
-        const uint32_t fo = f * kRawFrameBytes + col;                     // 32-bit lane offsets
-        o0 = mad_u24((uint32_t)y0, kRawRowBytes, fo);
-        o1 = mad_u24((uint32_t)y1, kRawRowBytes, fo);
+        const uint32_t fo = f * kFrameB + col;                            // 32-bit lane offsets
+        o0 = mad_u24((uint32_t)y0, kRowB, fo);
+        o1 = mad_u24((uint32_t)y1, kRowB, fo);
         d = (rj_raw < nvalid * rows && rg < RG) ? ((f * BR + dyl) * kRawW + g4 * 4) * 2 : -1;
     };
-    U3 w0[kIter], w1[kIter];
+    U3 w0[kIter], w1[kIter];                                              // GRAY uses .x only
     int dst[kIter];
 #pragma unroll
     for (int it = 0; it < kIter; ++it) {
         uint32_t o0, o1;
         row_offsets(it, o0, o1, dst[it]);
-        w0[it] = *reinterpret_cast<const U3 *>(fbase + o0);
-        w1[it] = *reinterpret_cast<const U3 *>(fbase + o1);
+        if (GRAY) {
+            w0[it].x = *reinterpret_cast<const uint32_t *>(fbase + o0);
+            w1[it].x = *reinterpret_cast<const uint32_t *>(fbase + o1);
+        } else {
+            w0[it] = *reinterpret_cast<const U3 *>(fbase + o0);
+            w1[it] = *reinterpret_cast<const U3 *>(fbase + o1);
+        }
     }
     const uint32_t cmd = uniform_load_u8(p.cmd + n);
     const int head = uniform_load_i32(p.head_in + n);
@@ -160,8 +169,8 @@ __device__ __forceinline__ void ingest_band(const IngestParams &p, const int ban
 #pragma unroll
         for (int it = 0; it < kIter; ++it) {
             bool tie = false;
-            const uint32_t top = lum4(w0[it].x, w0[it].y, w0[it].z, tie);
-            const uint32_t bot = lum4(w1[it].x, w1[it].y, w1[it].z, tie);
+            const uint32_t top = GRAY ? w0[it].x : lum4(w0[it].x, w0[it].y, w0[it].z, tie);
+            const uint32_t bot = GRAY ? w1[it].x : lum4(w1[it].x, w1[it].y, w1[it].z, tie);
             if (dst[it] >= 0) {
                 uint2 v;                                                  // t0 b0 t1 b1 | t2 b2 t3 b3
                 v.x = __builtin_amdgcn_perm(bot, top, 0x05010400u);
@@ -170,7 +179,7 @@ __device__ __forceinline__ void ingest_band(const IngestParams &p, const int ban
                 tie_its |= tie ? (1u << it) : 0u;
             }
         }
-        if (__builtin_expect(tie_its != 0, 0)) {
+        if (!GRAY && __builtin_expect(tie_its != 0, 0)) {
             // about 1e-4 of random pixels sit on an exact .5 tie: redo those pieces byte by byte with
             // the exact rule.  The source bytes are re-read (L2 hits) so that the fast path does not
             // have to keep 24 registers alive for this branch.
@@ -249,6 +258,12 @@ template <int T>
 __global__ __launch_bounds__(T) void k_ingest(IngestParams p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     ingest_band<T>(p, blockIdx.x, blockIdx.y, smem);
+}
+
+// K1g: the same from ALE grayscale screens u8 [N][2][210][160] (agx_ingest_gray_raw)
+__global__ __launch_bounds__(kThreads) void k_ingest_grayraw(IngestParams p) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    ingest_band<kThreads, true>(p, blockIdx.x, blockIdx.y, smem);
 }
 
 // ---------------------------------------------------------------------------------------------

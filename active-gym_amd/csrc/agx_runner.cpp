@@ -5,6 +5,7 @@
 
 #include <algorithm>
 #include <atomic>
+#include <cmath>
 #include <condition_variable>
 #include <cstdarg>
 #include <cstdio>
@@ -28,6 +29,7 @@ struct Emulator {
     virtual int lives() = 0;
     virtual void reset_game() = 0;
     virtual void screen_rgb(uint8_t *out) = 0; // [210][160][3]
+    virtual void screen_gray(uint8_t *out) = 0; // [210][160]  ALE getScreenGrayscale
     virtual std::vector<int> minimal_actions() = 0;
 };
 
@@ -83,6 +85,27 @@ struct ScriptedEmu final : Emulator {
                 p[2] = (uint8_t)((base + 58u + (K >> 3)) & 0xFF);
             }
     }
+    void screen_gray(uint8_t *out) override {                 // what ALE's palette would give for these RGB values
+        const uint32_t K = (uint32_t)((seed * 1000003ull + (uint64_t)episode * 7919ull + (uint64_t)frame * 31ull) & 0xFFFFu);
+        // r, g, b are functions of (base & 0xFF) for a given K: one 256-entry table per screen, like ALE's palette
+        uint8_t lut[256];
+        for (uint32_t v8 = 0; v8 < 256; ++v8) {
+            const uint32_t r = v8, g = (v8 + 29u) & 0xFF, b = (v8 + 58u + (K >> 3)) & 0xFF;
+            // round(.2989 r + .5870 g + .1140 b): the rational value decides, except on exact .5 ties, where
+            // ALE's double expression is evaluated as written
+            const uint32_t t = 2989u * r + 5870u * g + 1140u * b + 5000u;
+            uint32_t q = t / 10000u;
+            if (t % 10000u == 0u) {
+                const double v = ((double)r * 0.2989 + (double)g * 0.5870) + (double)b * 0.1140;
+                const double fl = std::floor(v);
+                q = (uint32_t)fl + ((v - fl) >= 0.5 ? 1u : 0u);
+            }
+            lut[v8] = (uint8_t)q;
+        }
+        for (int y = 0; y < kH; ++y)
+            for (int x = 0; x < kW; ++x)
+                out[(size_t)y * kW + x] = lut[((uint32_t)(y * 7 + x * 13) + K * 3u + (uint32_t)((y * x) >> 4)) & 0xFF];
+    }
     std::vector<int> minimal_actions() override {
         std::vector<int> v(n_actions);
         for (int i = 0; i < n_actions; ++i) v[i] = i;
@@ -106,6 +129,7 @@ struct AleApi {
     int (*getMinimalActionSize)(void *) = nullptr;
     void (*getMinimalActionSet)(void *, int *) = nullptr;
     void (*getScreenRGB)(void *, unsigned char *) = nullptr;
+    void (*getScreenGrayscale)(void *, unsigned char *) = nullptr;
     std::string load(const char *path) {
         lib = dlopen(path, RTLD_NOW | RTLD_LOCAL);
         if (!lib) return std::string("dlopen failed: ") + dlerror();
@@ -113,7 +137,7 @@ struct AleApi {
     name = reinterpret_cast<decltype(name)>(dlsym(lib, #name));                \
     if (!name) return std::string("libale_c symbol missing: ") + #name;
         SYM(ALE_new) SYM(ALE_del) SYM(setInt) SYM(setFloat) SYM(setBool) SYM(loadROM) SYM(act) SYM(game_over)
-        SYM(reset_game) SYM(lives) SYM(getMinimalActionSize) SYM(getMinimalActionSet) SYM(getScreenRGB)
+        SYM(reset_game) SYM(lives) SYM(getMinimalActionSize) SYM(getMinimalActionSet) SYM(getScreenRGB) SYM(getScreenGrayscale)
 #undef SYM
         return "";
     }
@@ -136,6 +160,7 @@ struct AleEmu final : Emulator {
     int lives() override { return api->lives(ale); }
     void reset_game() override { api->reset_game(ale); }
     void screen_rgb(uint8_t *out) override { api->getScreenRGB(ale, out); }
+    void screen_gray(uint8_t *out) override { api->getScreenGrayscale(ale, out); }
     std::vector<int> minimal_actions() override {
         std::vector<int> v(api->getMinimalActionSize(ale));
         api->getMinimalActionSet(ale, v.data());
@@ -302,14 +327,16 @@ static void step_env(agxr_runner *r, int i, const int32_t *motor, uint8_t *frame
     const int a = r->actions[i][motor[i]];
     int rew = 0, nvalid = 0;
     bool d = false;
-    uint8_t *f = frames + (size_t)i * 2 * kFrameBytes;
+    const size_t fb = r->cfg.gray_frames ? (size_t)kH * kW : (size_t)kFrameBytes;
+    const bool gray = r->cfg.gray_frames != 0;
+    uint8_t *f = frames + (size_t)i * 2 * fb;
     for (int t = 0; t < r->cfg.action_repeat; ++t) {          // atari_env.py:123-131
         rew += e.act(a);
         if (t == 2) {
-            e.screen_rgb(f);
+            if (gray) e.screen_gray(f); else e.screen_rgb(f);
             nvalid = 1;
         } else if (t == 3) {
-            e.screen_rgb(f + kFrameBytes);
+            if (gray) e.screen_gray(f + fb); else e.screen_rgb(f + fb);
             nvalid = 2;
         }
         d = e.game_over();
@@ -414,7 +441,8 @@ int agxr_reset(agxr_runner *r, const int32_t *idx, int32_t k, const int32_t *noo
                 }
                 if (e.game_over()) e.reset_game();
             }
-            e.screen_rgb(frames + (size_t)i * env_stride);
+            if (r->cfg.gray_frames) e.screen_gray(frames + (size_t)i * env_stride);
+            else e.screen_rgb(frames + (size_t)i * env_stride);
             r->lives[i] = e.lives();
             cmd[i] = (uint8_t)(1 | clear);
         }

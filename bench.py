@@ -39,6 +39,9 @@ def parse():
     ap.add_argument("--pool", type=int, default=8, help="distinct synthetic input batches cycled through")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="budget of the CPU-baseline sample")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--frame-format", default="rgb", choices=("rgb", "gray"),
+                    help="rgb = the metric's workload (raw RGB screens, luminance on the device); gray = ALE grayscale "
+                         "screens in (agx_ingest_gray_raw) - a different, lighter workload, reported for DESIGN.md only")
     ap.add_argument("--no-events", action="store_true", help="skip per-kernel HIP events in the timed region")
     ap.add_argument("--fused", action="store_true",
                     help="fixed kind: use agx_step_fixed's heterogeneous launch (sets AGX_STEP_FUSED=1; measured a tie)")
@@ -48,14 +51,14 @@ def parse():
     return ap.parse_args()
 
 
-def synth_inputs(torch, dev, n, pool, seed):
+def synth_inputs(torch, dev, n, pool, seed, gray=False):
     """Synthetic Atari-shaped inputs: i.i.d. uniform u8 RGB frames, 0.1% of env-steps
     with fewer than two sampled frames, 0.1% full resets, absolute actions uniform in [-5, 60)."""
     g = torch.Generator(device=dev)
     g.manual_seed(seed)
     frames, cmds, acts = [], [], []
     for _ in range(pool):
-        frames.append(torch.randint(0, 256, (n, 2, 210, 160, 3), dtype=torch.uint8, device=dev, generator=g))
+        frames.append(torch.randint(0, 256, (n, 2, 210, 160) + (() if gray else (3,)), dtype=torch.uint8, device=dev, generator=g))
         u = torch.rand((n,), device=dev, generator=g)
         nvalid = torch.full((n,), 2, dtype=torch.uint8, device=dev)
         nvalid[u < 0.001] = 1
@@ -225,7 +228,9 @@ def main():
 
     n = args.envs
     pipe = make_pipeline(args.kind, n, dev)
-    frames, cmds, acts = synth_inputs(torch, dev, n, args.pool, 1234 + rank)
+    gray = args.frame_format == "gray"
+    frames, cmds, acts = synth_inputs(torch, dev, n, args.pool, 1234 + rank, gray)
+    ingest = pipe.ingest_gray_raw if gray else pipe.ingest
     types = None
     if args.kind == "flexible":
         g = torch.Generator(device=dev)
@@ -249,7 +254,7 @@ def main():
             # launch 1: ingest bands + fovea of the untouched ring slots; launch 2: fovea of the written slot
             pipe.step_fixed(frames[i], cmds[i], acts[i], out=obs, loc_out=loc, mid_event=None if e is None else e[1])
         else:
-            pipe.ingest(frames[i], cmds[i])
+            ingest(frames[i], cmds[i])
             if e is not None:
                 e[1].record()
             if types is None:
@@ -289,13 +294,13 @@ def main():
         if use_ev:
             t_ing = sum(e[0].elapsed_time(e[1]) for e in ev.values()) / len(ev) * 1e-3
             t_fov = sum(e[1].elapsed_time(e[2]) for e in ev.values()) / len(ev) * 1e-3
-            b_ing, b_fov = pipe.algorithmic_bytes("ingest"), pipe.algorithmic_bytes("fovea")
+            b_ing, b_fov = pipe.algorithmic_bytes("ingest_gray_raw" if gray else "ingest"), pipe.algorithmic_bytes("fovea")
             if fused:
                 fs = pipe.frame_stack
                 plan = (("k_step_fixed (ingest + fovea of the %d untouched ring slots)" % (fs - 1), b_ing + b_fov * (fs - 1) // fs, t_ing),
                         ("k_fovea_fixed (written slot)", b_fov // fs, t_fov))
             else:
-                plan = (("k_ingest", b_ing, t_ing), ("k_fovea_" + args.kind, b_fov, t_fov))
+                plan = (("k_ingest_grayraw" if gray else "k_ingest", b_ing, t_ing), ("k_fovea_" + args.kind, b_fov, t_fov))
             for name, b, t in plan:
                 kernels[name] = {"avg_us": t * 1e6, "algorithmic_bytes": b, "achieved_GBps": b / t / 1e9,
                                  "frac": b / t / 1e9 / HBM_PEAK_GBS}
@@ -316,7 +321,8 @@ def main():
             "dtype": "u8 ingest / f32 resize", "data": "synthetic",
             "config": {"workload": f"{n}x AtariFixedFovealEnv-shaped envs per GPU (kind={args.kind}), 84x84 obs, 30x30 fov, "
                                    "frame_stack=4, action_repeat=4, resize_to_full, absolute sensory actions; "
-                                   "device-resident synthetic RGB frames (BASELINE.json configs[1])",
+                                   + ("device-resident synthetic RGB frames (BASELINE.json configs[1])" if not gray else
+                                      "device-resident synthetic GRAY screens (getScreenGrayscale format) - NOT the metric's workload"),
                        "envs_per_gpu": n, "total_envs": total_envs, "input_pool": args.pool,
                        "parallelism": f"env-shard x{world}, no collective"},
             "roofline": roof, "kernels": kernels,

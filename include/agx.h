@@ -82,6 +82,7 @@ extern "C" {
 #define AGX_K_FOVEA       2   /* the context's own fovea kernel (fixed / flexible / peripheral) */
 #define AGX_K_FULL        3
 #define AGX_K_INGEST_RGB  4   /* agx_ingest_rgb */
+#define AGX_K_INGEST_GRAY_RAW 5 /* agx_ingest_gray_raw */
 
 typedef struct agx_ctx agx_ctx;
 
@@ -138,6 +139,11 @@ AGX_API int64_t agx_algorithmic_bytes(const agx_ctx *ctx, int kernel_id);
  * d_cmd   : u8 [N] command bytes (AGX_CMD_*)
  * The stack is kept as u8 numerators k of the reference's float32 k/255. */
 AGX_API int agx_ingest(agx_ctx *ctx, const uint8_t *d_frames, const uint8_t *d_cmd, void *stream);
+
+/* Same as agx_ingest, but from ALE's own grayscale screens: d_gray u8 [N][2][raw_h][raw_w] as
+ * `ale.getScreenGrayscale()` returns them - what the reference itself reads (atari_env.py:74).  No luminance
+ * arithmetic on the device (ALE's palette table has done it) and a third of the bytes over PCIe and HBM. */
+AGX_API int agx_ingest_gray_raw(agx_ctx *ctx, const uint8_t *d_gray, const uint8_t *d_cmd, void *stream);
 
 /* Same append, but from frames that are already obs-sized gray u8
  * [N][2][obs_h][obs_w] (sources that render at obs_size, e.g. the DMC path

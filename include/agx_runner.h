@@ -50,6 +50,9 @@ typedef struct agxr_config {
     const char *backend;       /* "scripted" | "ale_c" */
     const char *ale_lib;       /* path of libale_c.so ("ale_c") */
     const char *rom_path;      /* ROM file ("ale_c") */
+    int32_t gray_frames;       /* 0: RGB screens u8[N][2][210][160][3] (agx_ingest); 1: ALE grayscale screens
+                                  u8[N][2][210][160] (getScreenGrayscale, what the reference reads; agx_ingest_gray_raw) */
+    int32_t reserved;
 } agxr_config;
 
 AGXR_API int agxr_create(const agxr_config *cfg, agxr_runner **out);
@@ -60,7 +63,7 @@ AGXR_API void agxr_set_training(agxr_runner *r, int training);   /* AtariEnv.tra
 
 /* One AtariEnv._step per env (atari_env.py:119-148).
  *   motor   i32[N]  index into the minimal action set
- *   frames  u8 [N][2][210][160][3]  the screens after t==2 / t==3 go to slots 0 / 1
+ *   frames  u8 [N][2][210][160][3] (or [N][2][210][160] with gray_frames)  the screens after t==2 / t==3 go to slots 0 / 1
  *   cmd     u8 [N]  nvalid for agx_ingest
  *   reward  f64[N]  sign(raw) if clip_reward else raw;  raw f64[N];  done u8[N] (incl. life-loss terminals) */
 AGXR_API int agxr_step(agxr_runner *r, const int32_t *motor, uint8_t *frames, uint8_t *cmd, double *reward,

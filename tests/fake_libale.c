@@ -93,3 +93,12 @@ void getScreenRGB(void *p, unsigned char *out) {
             q[2] = (unsigned char)((base + 58u + (K >> 3)) & 0xFF);
         }
 }
+void getScreenGrayscale(void *p, unsigned char *out) {
+    static __thread unsigned char rgb[210 * 160 * 3];
+    getScreenRGB(p, rgb);
+    for (int i = 0; i < 210 * 160; ++i) {
+        double x = ((double)rgb[3 * i] * 0.2989 + (double)rgb[3 * i + 1] * 0.5870) + (double)rgb[3 * i + 2] * 0.1140;
+        double fl = (double)(long)x;
+        out[i] = (unsigned char)(fl + ((x - fl) >= 0.5 ? 1.0 : 0.0));
+    }
+}

@@ -59,3 +59,10 @@ class LcgALE:
         out[..., 1] = (base + 29) & 0xFF
         out[..., 2] = (base + 58 + (K >> 3)) & 0xFF
         return out
+
+    def getScreenGrayscale(self):
+        """(210, 160, 1) like atari_py: ALE's luminance of these RGB values, C-double arithmetic in ALE's order."""
+        rgb = self.getScreenRGB().astype(np.float64)
+        x = (rgb[..., 0] * 0.2989 + rgb[..., 1] * 0.5870) + rgb[..., 2] * 0.1140
+        fl = np.floor(x)
+        return (fl + ((x - fl) >= 0.5)).astype(np.uint8)[..., None]

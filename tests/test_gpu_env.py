@@ -41,7 +41,8 @@ def _oracle_env(i, args, noop_iter, kind, antialias=True):
         ale = ScriptedALE(seed=300 + i, n_actions=4, p_life=0.05, p_over=0.01)
     env = O.AtariEnvOracle(ale, ale.getMinimalActionSet(), obs_size=(84, 84), frame_stack=args.frame_stack,
                            action_repeat=args.action_repeat, clip_reward=args.clip_reward,
-                           noop_fn=lambda: int(next(noop_iter)), prefer_rgb=True)
+                           noop_fn=lambda: int(next(noop_iter)),
+                           prefer_rgb=getattr(args, "frame_format", "rgb") != "gray")   # gray: ale.getScreenGrayscale(), as the reference
     rec = O.RecordOracle(env)
     if kind == "base":
         return rec, None
@@ -68,6 +69,11 @@ def _oracle_env(i, args, noop_iter, kind, antialias=True):
                    scripted_p_over=10, h2d_chunk_envs=2)),        # chunked: H2D of chunk c overlaps emulation of c+1
     ("flexible", dict(resize_to_full=False, mask_out=True, frame_source="native", scripted_actions=4, scripted_lives=2,
                       scripted_p_life=50, scripted_p_over=10, clip_reward=True)),
+    # frame_format="gray": the emulator's own grayscale screens travel (getScreenGrayscale, atari_env.py:74); the
+    # scripted emulator's gray is a channel mean, i.e. independent of the luminance restatement
+    ("fixed", dict(resize_to_full=True, frame_format="gray")),
+    ("peripheral", dict(resize_to_full=False, peripheral_res=(20, 20), frame_format="gray", frame_source="native",
+                        scripted_actions=4, scripted_lives=3, scripted_p_life=50, scripted_p_over=10, h2d_chunk_envs=3)),
 ])
 def test_vec_env_matches_oracle_with_autoreset(kind, extra):
     from active_gym import AtariVecEnv

@@ -537,6 +537,52 @@ def test_step_fixed_equals_separate_calls(dev, geom, monkeypatch):
                 orcs[i].update_loc(act_np[i])
 
 
+# ---------------------------------------------------------------- K1g: ALE grayscale screens in
+@pytest.mark.parametrize("obs", [(84, 84), (64, 64)])
+def test_ingest_gray_raw_matches_oracle_and_rgb_path(dev, obs):
+    """agx_ingest_gray_raw takes getScreenGrayscale screens (what the reference itself resizes, atari_env.py:74):
+    bit-exact against the oracle's OpenCV restatement on arbitrary gray input, and - when the gray screens are
+    ALE's luminance of RGB screens - identical to the RGB path's ring."""
+    N, fs = 21, 4
+    g = _pipe(num_envs=N, kind="base", obs_size=obs, frame_stack=fs)
+    c = _pipe(num_envs=N, kind="base", obs_size=obs, frame_stack=fs)
+    rng = np.random.default_rng(31)
+    ring = np.zeros((N, fs) + obs, np.uint8)
+    for step in range(6):
+        rgb = rng.integers(0, 256, (N, 2, 210, 160, 3), dtype=np.uint8)
+        gray = O.ale_luminance(rgb) if step % 2 == 0 else rng.integers(0, 256, (N, 2, 210, 160), dtype=np.uint8)
+        nvalid = rng.integers(0, 3, N)
+        clear = (rng.random(N) < 0.2).astype(np.uint8)
+        skip = (rng.random(N) < 0.15).astype(np.uint8)
+        nvalid[clear == 1] = 1
+        cmd = _t((nvalid | clear * 4 | skip * 8).astype(np.uint8), dev)
+        g.ingest_gray_raw(_t(gray, dev), cmd)
+        for i in range(N):
+            if skip[i]:
+                continue
+            if clear[i]:
+                ring[i] = 0
+            new = np.zeros(obs, np.uint8)
+            for f in range(int(nvalid[i])):
+                new = np.maximum(new, O.cv_resize_linear_u8(gray[i, f], obs))
+            ring[i] = np.concatenate([ring[i, 1:], new[None]], 0)
+        assert np.array_equal(g.stack_u8().cpu().numpy(), ring), step
+    # same screens through both front ends
+    a = _pipe(num_envs=N, kind="base", obs_size=obs, frame_stack=fs)
+    b = _pipe(num_envs=N, kind="base", obs_size=obs, frame_stack=fs)
+    for step in range(3):
+        rgb = rng.integers(0, 256, (N, 2, 210, 160, 3), dtype=np.uint8)
+        cmd = _t(np.full(N, 2 | (4 if step == 0 else 0), np.uint8), dev)
+        a.ingest(_t(rgb, dev), cmd)
+        b.ingest_gray_raw(_t(O.ale_luminance(rgb), dev), cmd)
+        assert torch.equal(a.stack_u8(), b.stack_u8())
+    assert g.algorithmic_bytes("ingest_gray_raw") * 3 - 2 * N * obs[0] * obs[1] == g.algorithmic_bytes("ingest")
+    with pytest.raises(ValueError):
+        g.ingest_gray_raw(_t(np.zeros((N, 2, 210, 160, 3), np.uint8), dev), cmd)
+    for p_ in (g, c, a, b):
+        p_.close()
+
+
 # ---------------------------------------------------------------- every tuning variant == the default, bit for bit
 _KNOBS = ("AGX_INGEST_T", "AGX_INGEST_BAND_ROWS", "AGX_INGEST_PIPE", "AGX_INGEST_WAVE", "AGX_FOVEA_PAIR", "AGX_STEP_FUSED",
           "AGX_FOVEA_GENERIC")

@@ -164,3 +164,35 @@ def test_ale_c_backend_through_a_stand_in_libale(tmp_path, monkeypatch):
     with pytest.raises(RuntimeError, match="dlopen|symbol"):
         monkeypatch.setattr(nr, "_find_libale_c", lambda: (str(tmp_path / "missing.so"), fake))
         nr.NativeHostRunner(_Args(**common), 1, backend="ale_c")
+
+
+def test_gray_frames_native_equals_python_runner():
+    """frame_format="gray": both runners hand over ALE-style grayscale screens u8[N,2,210,160] (what the reference
+    reads, atari_env.py:74); for the scripted emulator gray == ALE luminance of its RGB screen."""
+    _build()
+    from active_gym.native_runner import NativeHostRunner
+    from active_gym.runner import AtariHostRunner
+    from oracle import oracle as O
+    N = 3
+    common = dict(game="g", seed=9, action_repeat=4, clip_reward=False, max_episode_length=108e3, frame_format="gray",
+                  scripted_p_life=40, scripted_p_over=10)
+    py = AtariHostRunner(_Args(frame_source=lambda a, i: LcgALE(9 + i, 4, 3, 40, 10), **common), N, workers=1, noop_fn=lambda: 2)
+    nv = NativeHostRunner(_Args(**common), N, workers=2, noop_fn=lambda: 2, backend="scripted")
+    assert py.frames.shape == nv.frames.shape == (N, 2, 210, 160)
+    assert np.array_equal(py.reset(), nv.reset()) and np.array_equal(py.frames[:, 0], nv.frames[:, 0])
+    e = LcgALE(9, 4, 3, 40, 10)
+    assert np.array_equal(e.getScreenGrayscale()[..., 0], O.ale_luminance(e.getScreenRGB()))
+    rng = np.random.default_rng(2)
+    for step in range(40):
+        m = rng.integers(0, 4, N)
+        a, b = py.step(m), nv.step(m)
+        for x, y in zip(a, b):
+            assert np.array_equal(x, y)
+        for i in range(N):
+            for s_ in range(int(a[2][i])):
+                assert np.array_equal(py.frames[i, s_], nv.frames[i, s_])
+        d = np.nonzero(a[1])[0]
+        if len(d):
+            ra = np.zeros((N, 1, 210, 160), np.uint8); rb = np.zeros_like(ra)
+            assert np.array_equal(py.reset(d, out=ra), nv.reset(d, out=rb)) and np.array_equal(ra, rb)
+    py.close(); nv.close()

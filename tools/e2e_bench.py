@@ -26,8 +26,8 @@ def best(fn):
     return min(out)
 
 
-def mk(src, chunk, workers):
-    return AtariEnvArgs(game="breakout", seed=1, obs_size=(84, 84), fov_size=(30, 30), fov_init_loc=(0, 0),
+def mk(src, chunk, workers, fmt="rgb"):
+    return AtariEnvArgs(frame_format=fmt, game="breakout", seed=1, obs_size=(84, 84), fov_size=(30, 30), fov_init_loc=(0, 0),
                         sensory_action_mode="absolute", resize_to_full=True, frame_source=src, device="cuda",
                         num_workers=workers, h2d_chunk_envs=chunk)
 
@@ -45,13 +45,14 @@ d = torch.empty_like(h, device="cuda")
 dt = best(lambda: d.copy_(h, non_blocking=True))
 print(f"H2D only ({h.numel() / 1e6:.0f} MB): {dt * 1e3:.2f} ms/step = {h.numel() / dt / 1e9:.1f} GB/s", flush=True)
 act = {"motor_action": m, "sensory_action": np.full((N, 2), 20.0, np.float32)}
-for src, chunk, w in (("native", 0, 64), ("native", 256, 64), ("native", 128, 64), ("native", 64, 64), ("native", 128, 128),
-                      ("native", 128, 32), ("native", 64, 16), ("synthetic", 0, 16)):
-    env = AtariVecEnv(mk(src, chunk, w), N, kind="fixed")
+for src, chunk, w, fmt in (("native", 0, 64, "rgb"), ("native", 128, 64, "rgb"), ("native", 256, 64, "rgb"), ("native", 0, 64, "gray"),
+                           ("native", 128, 64, "gray"), ("native", 256, 64, "gray"), ("native", 128, 128, "gray"),
+                           ("synthetic", 0, 16, "rgb")):
+    env = AtariVecEnv(mk(src, chunk, w, fmt), N, kind="fixed")
     env.reset()
     if src == "synthetic":
         steps, reps = 3, 1
     env.step(act)
     dt = best(lambda: env.step(act))
-    print(f"e2e {src:9s} workers={w:3d} chunk={chunk:4d} N={N}: {dt * 1e3:6.2f} ms/step {N / dt:10,.0f} env steps/s", flush=True)
+    print(f"e2e {src:9s} {fmt:4s} workers={w:3d} chunk={chunk:4d} N={N}: {dt * 1e3:6.2f} ms/step {N / dt:10,.0f} env steps/s", flush=True)
     env.close()
