@@ -7,7 +7,8 @@ from __future__ import annotations
 import numpy as np
 
 try:  # pragma: no cover - gymnasium is absent from the build image
-    from gymnasium.spaces import Box, Dict, Discrete  # type: ignore
+    from gymnasium.spaces import Box, Dict, Discrete, MultiDiscrete  # type: ignore
+    from gymnasium.vector.utils import batch_space  # type: ignore
     HAVE_GYMNASIUM = True
 except Exception:  # noqa: BLE001
     HAVE_GYMNASIUM = False
@@ -85,3 +86,32 @@ except Exception:  # noqa: BLE001
 
         def __repr__(self):
             return "Dict(" + ", ".join(f"{k!r}: {v!r}" for k, v in self.items()) + ")"
+
+    class MultiDiscrete(_Space):
+        def __init__(self, nvec, dtype=np.int64):
+            super().__init__()
+            self.nvec = np.asarray(nvec, dtype=dtype)
+            self.shape = self.nvec.shape
+            self.dtype = np.dtype(dtype)
+
+        def sample(self):
+            return (self._rng.random(self.shape) * self.nvec).astype(self.dtype)
+
+        def contains(self, x):
+            x = np.asarray(x)
+            return x.shape == self.shape and bool(np.all(x >= 0) and np.all(x < self.nvec))
+
+        def __repr__(self):
+            return f"MultiDiscrete({self.nvec.tolist()})"
+
+    def batch_space(space, n=1):
+        """gymnasium.vector.utils.batch_space for the three space kinds used here: what SyncVectorEnv exposes as
+        ``action_space`` / ``observation_space`` (the per-env spaces stay under ``single_*``)."""
+        if isinstance(space, Box):
+            rep = (n,) + (1,) * len(space.shape)
+            return Box(low=np.tile(space.low, rep), high=np.tile(space.high, rep), dtype=space.dtype)
+        if isinstance(space, Discrete):
+            return MultiDiscrete(np.full((n,), space.n, dtype=np.int64))
+        if isinstance(space, Dict):
+            return Dict({k: batch_space(v, n) for k, v in space.items()})
+        raise TypeError(f"cannot batch {space!r}")

@@ -25,7 +25,7 @@ import torch
 from . import _native as nat
 from .pipeline import ObsPipeline
 from .runner import AtariHostRunner
-from .spaces import Box, Dict, Discrete
+from .spaces import Box, Dict, Discrete, batch_space
 
 _KINDS = ("base", "fixed", "flexible", "peripheral")
 
@@ -106,8 +106,9 @@ class AtariVecEnv:
             crop = kind == "fixed" and not (self.mask_out or self.resize_to_full)
             shp = (self.frame_stack,) + (self.fov_size if crop else self.obs_size)
             self.single_observation_space = Box(low=-1., high=1., shape=shp, dtype=np.float32)
-        self.action_space = self.single_action_space
-        self.observation_space = self.single_observation_space
+        # SyncVectorEnv conventions (gymnasium<1.0): batched spaces under action_space / observation_space
+        self.action_space = batch_space(self.single_action_space, self.num_envs)
+        self.observation_space = batch_space(self.single_observation_space, self.num_envs)
 
         # RecordWrapper bookkeeping (fov_env.py:29-32,58-63)
         self.cumulative_reward = np.zeros(self.num_envs, np.float64)

@@ -20,6 +20,9 @@ from active_gym import AtariEnvArgs, AtariFixedFovealEnv, AtariVecEnv  # noqa: E
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--ale", action="store_true", help="use real ALE through atari_py / ale_py instead of the stand-in")
+    ap.add_argument("--native", action="store_true",
+                    help="batched part: the C++ thread-per-core host runner (libagx_runner.so; scripted emulator, or real "
+                         "ALE with --ale) with grayscale screens and chunked H2D overlap")
     ap.add_argument("--envs", type=int, default=256)
     a = ap.parse_args()
     src = "ale" if a.ale else "synthetic"
@@ -40,9 +43,13 @@ def main():
     env.close()
 
     # --- N envs on one GPU, observations stay in HBM
+    extra = {}
+    if a.native:
+        src = "native:ale" if a.ale else "native"
+        extra = dict(frame_format="gray", h2d_chunk_envs=max(1, a.envs // 8))
     args = AtariEnvArgs(game="boxing", seed=0, obs_size=(84, 84), fov_size=(30, 30), fov_init_loc=(0, 0),
                         sensory_action_mode="relative", sensory_action_space=(-10.0, 10.0), resize_to_full=True,
-                        frame_source=src, device="cuda")
+                        frame_source=src, device="cuda", **extra)
     venv = AtariVecEnv(args, num_envs=a.envs, kind="fixed")
     obs, infos = venv.reset()
     t0 = time.perf_counter()
@@ -54,7 +61,8 @@ def main():
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
     print(f"vec env: {a.envs} envs, obs {tuple(obs.shape)} on {obs.device}; {a.envs * steps / dt:.0f} env steps/s end to end "
-          f"(host emulators + PCIe + kernels; the {src} emulators run in Python threads)")
+          f"(host emulators + PCIe + kernels; frame source: {src}"
+          + ("" if a.native else "; these emulators run in Python threads, try --native") + ")")
     venv.close()
 
 

@@ -224,6 +224,10 @@ def test_device_outputs_and_synthetic_source():
     env = AtariVecEnv(args, 16, kind="fixed")
     obs, infos = env.reset()
     assert isinstance(obs, torch.Tensor) and obs.is_cuda and obs.shape == (16, 4, 84, 84)
+    # SyncVectorEnv conventions: batched spaces, per-env spaces under single_*
+    assert env.observation_space.shape == (16, 4, 84, 84) and env.single_observation_space.shape == (4, 84, 84)
+    assert env.action_space["motor_action"].nvec.tolist() == [env.single_action_space["motor_action"].n] * 16
+    assert env.action_space["sensory_action"].shape == (16,) and env.single_action_space["sensory_action"].shape == ()
     for _ in range(5):
         a = {"motor_action": np.random.randint(0, 4, 16), "sensory_action": torch.rand(16, 2, device="cuda") * 54}
         obs, r, d, t, infos = env.step(a)

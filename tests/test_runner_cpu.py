@@ -133,3 +133,15 @@ def test_frame_source_ale_missing_is_loud():
         make_emulator(AtariEnvArgs(game="breakout", seed=0, obs_size=(84, 84)))
     e = make_emulator(AtariEnvArgs(game="breakout", seed=0, obs_size=(84, 84), frame_source="synthetic"))
     assert isinstance(e, SyntheticALE) and e.getScreenRGB().shape == (210, 160, 3)
+
+
+def test_batch_space_fallback_matches_gymnasium_conventions():
+    from active_gym import spaces as sp
+    if sp.HAVE_GYMNASIUM:
+        pytest.skip("gymnasium present: its own batch_space is used")
+    single = sp.Dict({"motor_action": sp.Discrete(6), "sensory_action": sp.Box(low=54, high=54, dtype=int),
+                      "obs": sp.Box(low=-1.0, high=1.0, shape=(4, 8, 8), dtype=np.float32)})
+    b = sp.batch_space(single, 5)
+    assert b["motor_action"].nvec.tolist() == [6] * 5 and b["motor_action"].contains(np.array([0, 5, 3, 2, 1]))
+    assert b["sensory_action"].shape == (5,) and b["sensory_action"].low.tolist() == [54] * 5
+    assert b["obs"].shape == (5, 4, 8, 8) and b["obs"].dtype == np.float32 and b.sample()["obs"].shape == (5, 4, 8, 8)
