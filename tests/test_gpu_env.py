@@ -323,3 +323,48 @@ def test_spaces_and_attributes_match_reference(kind):
         if kind == "per":
             assert list(env.peripheral_res) == g["peripheral_res"] and bool(env.resize_to_full) == g["resize_to_full"]
         env.close()
+
+
+def test_config1_single_env_10k_steps_against_cpu_reference_path():
+    """BASELINE.json configs[0] / SURVEY §8d config 1: one Breakout-shaped AtariFixedFovealEnv, 84x84 / 30x30,
+    absolute integer sensory actions uniform in [0, 54]^2, 10 000 steps with resets - the drop-in single env against
+    the CPU reference path (the oracle chain), every step: reward / done / counters / fov_loc exact, observation
+    within 1e-5.  A soak for ring wrap-around, life-loss and full resets, and state drift."""
+    import active_gym
+    from lcg_ale import LcgALE
+    mk = lambda: LcgALE(123, 4, 5, 6, 1)                      # 4 actions (Breakout's minimal set), 5 lives
+    args = _args(game="breakout", seed=123, fov_size=(30, 30), fov_init_loc=(0, 0), sensory_action_mode="absolute",
+                 resize_to_full=True, frame_source=lambda a, i: mk())
+    env = active_gym.AtariFixedFovealEnv(args)
+    noops = _Noops(9)
+    env.unwrapped._core.runner.noop_fn = lambda: int(next(noops.a))
+    ale = mk()
+    base = O.AtariEnvOracle(ale, ale.getMinimalActionSet(), obs_size=(84, 84), frame_stack=4, action_repeat=4,
+                            clip_reward=False, noop_fn=lambda: int(next(noops.b)), prefer_rgb=True)
+    rec = O.RecordOracle(base)
+    fov = O.FixedFovealOracle(obs_size=(84, 84), fov_size=(30, 30), fov_init_loc=(0, 0), sensory_action_mode="absolute",
+                              resize_to_full=True)
+    rng = np.random.default_rng(2024)
+    o, info = env.reset()
+    s, oi = rec.reset()
+    np.testing.assert_allclose(o, fov.reset(s), rtol=0, atol=TOL)
+    episodes = life_resets = 0
+    worst = 0.0
+    for step in range(10000):
+        act = {"motor_action": int(rng.integers(0, 4)), "sensory_action": rng.integers(0, 55, size=2)}
+        o, r, d, tr, info = env.step(act)
+        s, r2, d2, _, oi = rec.step(act["motor_action"])
+        want = fov.step(s, act["sensory_action"])
+        assert r == r2 and d == d2 and tr is False, step
+        assert info["ep_len"] == oi["ep_len"] and info["reward"] == oi["reward"] and np.array_equal(info["fov_loc"], fov.fov_loc), step
+        worst = max(worst, float(np.abs(o - want).max()))
+        if d:
+            episodes += 1
+            life_resets += int(base.life_termination)
+            o, info = env.reset()
+            s, oi = rec.reset()
+            worst = max(worst, float(np.abs(o - fov.reset(s)).max()))
+            assert np.array_equal(info["fov_loc"], fov.fov_loc)
+    assert worst <= TOL, worst
+    assert episodes >= 20 and 0 < life_resets < episodes          # both reset paths were exercised
+    env.close()
