@@ -227,8 +227,8 @@ size_t flex2_lds(const agx_config &c, size_t tab_floats) {
     const size_t raw = ((size_t)c.obs_h * c.obs_w + 15) & ~(size_t)15;
     const size_t ae = (std::max((size_t)c.obs_h * c.fov_w, (size_t)c.fov_h * c.obs_w) + 3) & ~(size_t)3;
     const size_t b = ((size_t)c.fov_h * c.fov_w + 3) & ~(size_t)3;
-    const size_t cc = ((size_t)c.fov_h * c.obs_w + 3) & ~(size_t)3;
-    return 1024 + raw + (ae + b + cc + tab_floats) * sizeof(float);
+    const size_t cc = ((size_t)c.fov_h * c.obs_w + 3) & ~(size_t)3;      // C aliases the raw frame bytes
+    return 1024 + std::max(raw, cc * sizeof(float)) + (ae + b + tab_floats) * sizeof(float);
 }
 
 template <class T>

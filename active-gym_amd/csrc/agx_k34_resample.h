@@ -497,14 +497,17 @@ __global__ __launch_bounds__(kThreads) void k_fovea_flexible2(FlexParams g, FovP
         return;
     }
     const int fbytes = oh * ow, fwords = fbytes >> 2;
-    // LDS: lut[256] | raw[oh*ow] | AE[max(oh*fw, fh*ow)] | B[fh*fw] | C[fh*ow] | tables
+    // LDS: lut[256] | raw[oh*ow] aliased by C[fh*ow] | AE[max(oh*fw, fh*ow)] | B[fh*fw] | tables
+    // (C is written by P3, two barriers after P1's last read of the raw bytes; only the squeeze path has a C, and
+    //  it never looks at the raw frame again - the paste / crop outputs read C there)
     float *lut = reinterpret_cast<float *>(smem);
     unsigned char *raw = smem + 1024;
-    float *AE = reinterpret_cast<float *>(raw + ((fbytes + 15) & ~15));
+    float *C = reinterpret_cast<float *>(raw);
+    const int rc_bytes = max((fbytes + 15) & ~15, ((fh * ow + 3) & ~3) * 4);
+    float *AE = reinterpret_cast<float *>(raw + rc_bytes);
     const int ae_floats = (max(oh * fw, fh * ow) + 3) & ~3;
     float *B = AE + ae_floats;
-    float *C = B + ((fh * fw + 3) & ~3);
-    float *tabs = C + ((fh * ow + 3) & ~3);
+    float *tabs = B + ((fh * fw + 3) & ~3);
 
     // ---- round trips start now
     const uint32_t *fsrc = reinterpret_cast<const uint32_t *>(p.ring + ((size_t)n * p.fs + sl) * (size_t)fbytes);
