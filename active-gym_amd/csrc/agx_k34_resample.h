@@ -49,8 +49,10 @@ __device__ __forceinline__ float apply_tap(const PassDesc &d, const Tap &t, cons
 __device__ __forceinline__ void pass_w(const PassDesc &d, const Tap *tab, const float *src, float *dst,
                                        int rows, int tid) {
     const int total = rows * d.n_out;
+    const FastDiv dv(d.n_out);
     for (int i = tid; i < total; i += kThreads) {
-        const int y = i / d.n_out, x = i - y * d.n_out;
+        int y, x;
+        dv.divmod(i, y, x);
         dst[i] = apply_tap(d, tab[x], src + y * d.n_in, 1);
     }
 }
@@ -59,8 +61,10 @@ __device__ __forceinline__ void pass_w(const PassDesc &d, const Tap *tab, const 
 __device__ __forceinline__ void pass_h(const PassDesc &d, const Tap *tab, const float *src, float *dst,
                                        int cols, int tid) {
     const int total = d.n_out * cols;
+    const FastDiv dv(cols);
     for (int i = tid; i < total; i += kThreads) {
-        const int y = i / cols, x = i - y * cols;
+        int y, x;
+        dv.divmod(i, y, x);
         dst[i] = apply_tap(d, tab[y], src + x, cols);
     }
 }
@@ -124,6 +128,7 @@ __global__ __launch_bounds__(kThreads) void k_fovea_generic(GeomR g, FovParams p
     float *buf1 = buf0 + cap;
     Tap *tab = reinterpret_cast<Tap *>(buf1 + p.buf1_floats);
     const int ow4 = ow >> 2;
+    const FastDiv dv_ow4(ow4);
     float4 *out4 = reinterpret_cast<float4 *>(p.obs) + ((size_t)n * p.fs + j) * (size_t)(oh * ow4);
 
     if (KIND == AGX_KIND_PERIPHERAL) {
@@ -155,7 +160,7 @@ __global__ __launch_bounds__(kThreads) void k_fovea_generic(GeomR g, FovParams p
         build_taps(d, tab, tid);
         __syncthreads();
         for (int q = tid; q < oh * ow4; q += kThreads) {
-            const int row = q / ow4, x = (q - row * ow4) * 4;
+            const int row = dv_ow4.div(q), x = (q - row * ow4) * 4;
             const Tap t = tab[row];
             const bool in_r = row >= r && row < r + fh;
             float v[4];
@@ -210,7 +215,7 @@ __global__ __launch_bounds__(kThreads) void k_fovea_generic(GeomR g, FovParams p
         __syncthreads();
         const float4 *H4 = reinterpret_cast<const float4 *>(oth);
         for (int q = tid; q < oh * ow4; q += kThreads) {
-            const int row = q / ow4, x4 = q - row * ow4;
+            const int row = dv_ow4.div(q), x4 = q - row * ow4;
             const Tap t = tab[row];
             const float4 a = H4[t.lo * ow4 + x4];
             const float4 b = H4[t.aux * ow4 + x4];
@@ -223,7 +228,7 @@ __global__ __launch_bounds__(kThreads) void k_fovea_generic(GeomR g, FovParams p
     const int pr = (p.out_mode == AGX_OUT_MASK) ? r : 0;
     const int pc = (p.out_mode == AGX_OUT_MASK) ? c : 0;
     for (int q = tid; q < oh * ow4; q += kThreads) {
-        const int row = q / ow4, x = (q - row * ow4) * 4;
+        const int row = dv_ow4.div(q), x = (q - row * ow4) * 4;
         const int y = row - pr;
         float v[4] = {0.f, 0.f, 0.f, 0.f};
         if (y >= 0 && y < rh) {
@@ -327,6 +332,7 @@ __global__ __launch_bounds__(kThreads) void k_fovea_peripheral2(PerParams g, Fov
     __syncthreads();
 
     const int ow4 = ow >> 2;
+    const FastDiv dv_ow4(ow4), dv_pw(pw), dv_ow(ow);
     float4 *out4 = reinterpret_cast<float4 *>(p.obs) + ((size_t)n * p.fs + j) * (size_t)(oh * ow4);
     if (!g.same) {
         // pass 0: A[y][xp] = sum_k (w0[xp][k] / 255) * raw[y][lo + k]
@@ -372,7 +378,7 @@ __global__ __launch_bounds__(kThreads) void k_fovea_peripheral2(PerParams g, Fov
         __syncthreads();
         // pass 1: B[yp][xp] = sum_k w1[yp][k] * A[lo + k][xp]
         for (int i = tid; i < ph * pw; i += kThreads) {
-            const int yp = i / pw, xp = i - yp * pw;
+            const int yp = dv_pw.div(i), xp = i - yp * pw;
             const int2 ln = ln1_s[yp];
             const float *w = w1_s + yp * mt1;
             float acc = 0.f;
@@ -398,7 +404,7 @@ __global__ __launch_bounds__(kThreads) void k_fovea_peripheral2(PerParams g, Fov
         } else {
             const AxisTab &t = g.t[2];
             for (int i = tid; i < ph * ow; i += kThreads) {
-                const int yp = i / ow, x = i - yp * ow;
+                const int yp = dv_ow.div(i), x = i - yp * ow;
                 const int2 ln = t.ln[x];
                 const float *w = t.w + x * t.maxt;
                 float acc = 0.f;
@@ -411,7 +417,7 @@ __global__ __launch_bounds__(kThreads) void k_fovea_peripheral2(PerParams g, Fov
     // pass 3 fused with paste + store: out[row][x..x+3]
     const float4 *C4 = reinterpret_cast<const float4 *>(C);
     for (int q = tid; q < oh * ow4; q += kThreads) {
-        const int row = q / ow4, x4 = q - row * ow4, x = x4 * 4;
+        const int row = dv_ow4.div(q), x4 = q - row * ow4, x = x4 * 4;
         float4 o = make_float4(0.f, 0.f, 0.f, 0.f);
         const bool in_r = row >= r && row < r + fh;
         const bool all_fov = g.same || (in_r && x >= c && x + 3 < c + fw);
@@ -570,12 +576,13 @@ __global__ __launch_bounds__(kThreads) void k_fovea_flexible2(FlexParams g, FovP
     const unsigned char *win = raw + r * ow + c;
     const float kInv255 = 1.0f / 255.0f;          // resampling inputs only (<= 1 ulp from k/255); pasted pixels use lut
     const int ow4 = ow >> 2;
+    const FastDiv dv_ow4(ow4), dv_ow(ow), dv_fw(fw), dv_rw(rw);
     float4 *out4 = reinterpret_cast<float4 *>(p.obs) + ((size_t)n * p.fs + j) * (size_t)(oh * ow4);
 
     if (squeeze) {
         // P1: A[y][xf] = Wdwn(crop)      y < rh, xf < fw
         for (int i = tid; i < rh * fw; i += kThreads) {
-            const int y = i / fw, xf = i - y * fw;
+            const int y = dv_fw.div(i), xf = i - y * fw;
             const int2 ln = wd.ln[xf];
             const float *w = wd.w + xf * wd.maxt;
             const unsigned char *src = win + y * ow + ln.x;
@@ -586,13 +593,13 @@ __global__ __launch_bounds__(kThreads) void k_fovea_flexible2(FlexParams g, FovP
         __syncthreads();
         // P2: B[yf][xf] = Hdwn(A)
         for (int i = tid; i < fh * fw; i += kThreads) {
-            const int yf = i / fw, xf = i - yf * fw;
+            const int yf = dv_fw.div(i), xf = i - yf * fw;
             B[i] = tap_dot(hd, yf, AE + xf, fw);
         }
         __syncthreads();
         // P3: C[yf][x] = Wbck(B)         x < rw
         for (int i = tid; i < fh * rw; i += kThreads) {
-            const int yf = i / rw, x = i - yf * rw;
+            const int yf = dv_rw.div(i), x = i - yf * rw;
             C[yf * ow + x] = tap_dot(wb, x, B + yf * fw, 1);
         }
         __syncthreads();
@@ -602,45 +609,53 @@ __global__ __launch_bounds__(kThreads) void k_fovea_flexible2(FlexParams g, FovP
         // E[y][xo] = Wfin(src rows): src = C (fh rows) after a squeeze, else the crop itself (rh rows)
         const int erows = squeeze ? fh : rh;
         for (int i = tid; i < erows * ow; i += kThreads) {
-            const int y = i / ow, xo = i - y * ow;
+            const int y = dv_ow.div(i), xo = i - y * ow;
+            // the final resize is never a down-scale (r <= obs): one or two taps, unrolled with a zero second weight
             const int2 ln = wf.ln[xo];
             const float *w = wf.w + xo * wf.maxt;
-            float acc = 0.f;
+            const bool two = ln.y > 1;
+            const float w0 = w[0], w1 = two ? w[1] : 0.f;
+            const int i1 = two ? ln.x + 1 : ln.x;
+            float acc;
             if (squeeze) {
-                for (int k = 0; k < ln.y; ++k) acc = fmaf(w[k], C[y * ow + ln.x + k], acc);
+                acc = fmaf(w1, C[y * ow + i1], w0 * C[y * ow + ln.x]);
             } else {
-                const unsigned char *src = win + y * ow + ln.x;
-                for (int k = 0; k < ln.y; ++k) acc = fmaf(w[k], (float)src[k], acc);
-                acc *= kInv255;
+                const unsigned char *src = win + y * ow;
+                acc = fmaf(w1, (float)src[i1], w0 * (float)src[ln.x]) * kInv255;
             }
             AE[i] = acc;
         }
         __syncthreads();
         const float4 *E4 = reinterpret_cast<const float4 *>(AE);
         for (int q = tid; q < oh * ow4; q += kThreads) {
-            const int row = q / ow4, x4 = q - row * ow4;
+            const int row = dv_ow4.div(q), x4 = q - row * ow4;
+            // both H passes of this output are up-scales here (r <= obs; fov < r on the squeeze path): at most two
+            // taps each, unrolled with zero weights for a missing second tap - no per-lane trip counts
             const int2 lnf = hf.ln[row];
             const float *wfv = hf.w + row * hf.maxt;
+            const bool twof = lnf.y > 1;
+            const float fa[2] = {wfv[0], twof ? wfv[1] : 0.f};
+            const int ya[2] = {lnf.x, twof ? lnf.x + 1 : lnf.x};          // rows of the (virtual) rh-row image
             float4 o = make_float4(0.f, 0.f, 0.f, 0.f);
-            for (int a = 0; a < lnf.y; ++a) {
-                const int ya = lnf.x + a;                      // row of the (virtual) rh-row image
+#pragma unroll
+            for (int a = 0; a < 2; ++a) {
                 if (squeeze) {
-                    const int2 lnb = hb.ln[ya];
-                    const float *wbv = hb.w + ya * hb.maxt;
-                    for (int b = 0; b < lnb.y; ++b) {
-                        const float ww = wfv[a] * wbv[b];
-                        const float4 v = E4[(lnb.x + b) * ow4 + x4];
-                        o.x = fmaf(ww, v.x, o.x);
-                        o.y = fmaf(ww, v.y, o.y);
-                        o.z = fmaf(ww, v.z, o.z);
-                        o.w = fmaf(ww, v.w, o.w);
-                    }
+                    const int2 lnb = hb.ln[ya[a]];
+                    const float *wbv = hb.w + ya[a] * hb.maxt;
+                    const bool twob = lnb.y > 1;
+                    const float wb0 = fa[a] * wbv[0], wb1 = twob ? fa[a] * wbv[1] : 0.f;
+                    const float4 v0 = E4[lnb.x * ow4 + x4];
+                    const float4 v1 = E4[(twob ? lnb.x + 1 : lnb.x) * ow4 + x4];
+                    o.x = fmaf(wb1, v1.x, fmaf(wb0, v0.x, o.x));
+                    o.y = fmaf(wb1, v1.y, fmaf(wb0, v0.y, o.y));
+                    o.z = fmaf(wb1, v1.z, fmaf(wb0, v0.z, o.z));
+                    o.w = fmaf(wb1, v1.w, fmaf(wb0, v0.w, o.w));
                 } else {
-                    const float4 v = E4[ya * ow4 + x4];
-                    o.x = fmaf(wfv[a], v.x, o.x);
-                    o.y = fmaf(wfv[a], v.y, o.y);
-                    o.z = fmaf(wfv[a], v.z, o.z);
-                    o.w = fmaf(wfv[a], v.w, o.w);
+                    const float4 v = E4[ya[a] * ow4 + x4];
+                    o.x = fmaf(fa[a], v.x, o.x);
+                    o.y = fmaf(fa[a], v.y, o.y);
+                    o.z = fmaf(fa[a], v.z, o.z);
+                    o.w = fmaf(fa[a], v.w, o.w);
                 }
             }
             store_obs(&out4[q], o);
@@ -651,7 +666,7 @@ __global__ __launch_bounds__(kThreads) void k_fovea_flexible2(FlexParams g, FovP
     const int pr = (p.out_mode == AGX_OUT_MASK) ? r : 0;
     const int pc = (p.out_mode == AGX_OUT_MASK) ? c : 0;
     for (int q = tid; q < oh * ow4; q += kThreads) {
-        const int row = q / ow4, x = (q - row * ow4) * 4;
+        const int row = dv_ow4.div(q), x = (q - row * ow4) * 4;
         const int y = row - pr;
         float v[4] = {0.f, 0.f, 0.f, 0.f};
         if (y >= 0 && y < rh) {
