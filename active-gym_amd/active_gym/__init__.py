@@ -30,6 +30,6 @@ from .fov_env import (  # noqa: F401
     FixedFovealPeripheralEnv,
 )
 from .vector import AtariVecEnv  # noqa: F401
-from .sharding import shard_bounds, ShardedAtariVecEnv, make_vec_env  # noqa: F401
+from .sharding import shard_bounds, shard_game, ShardedAtariVecEnv, make_vec_env  # noqa: F401
 
 __version__ = "0.1.0"

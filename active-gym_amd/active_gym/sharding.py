@@ -20,6 +20,17 @@ def shard_bounds(num_envs: int, rank: int, world_size: int) -> Tuple[int, int]:
     return lo, lo + base + (1 if rank < rem else 0)
 
 
+def shard_game(game, rank: int):
+    """BASELINE.json configs[4] ("mixed Atari-57 games", one shard per GPU): ``args.game`` may be a list, rank g then
+    plays ``game[g % len(game)]`` - every env of one shard shares a game, hence one minimal action set and one
+    action space per vec env, as with the reference's per-game envs."""
+    if isinstance(game, (list, tuple)):
+        if not game:
+            raise ValueError("empty game list")
+        return game[rank % len(game)]
+    return game
+
+
 def env_rank_world():
     return int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1")), int(os.environ.get("LOCAL_RANK", "0"))
 
@@ -39,6 +50,11 @@ class ShardedAtariVecEnv:
         self.lo, self.hi = shard_bounds(num_envs, self.rank, self.world_size)
         if getattr(args, "device", None) is None or str(args.device) == "cuda":
             torch.cuda.set_device(self.local_rank)
+        if isinstance(getattr(args, "game", None), (list, tuple)):
+            import copy
+            args = copy.copy(args)
+            args.game = shard_game(args.game, self.rank)
+        self.game = getattr(args, "game", None)
         self.env = AtariVecEnv(args, self.hi - self.lo, kind=kind, env_offset=self.lo, **kw)
 
     def __getattr__(self, name):

@@ -84,3 +84,12 @@ def test_two_rank_gloo_shards_reproduce_unsharded(tmp_path):
     outs = [p.communicate(timeout=240)[0] for p in procs]
     assert all(p.returncode == 0 for p in procs), "\n".join(outs)
     assert "SHARD_OK" in outs[0]
+
+
+def test_shard_game_mix():
+    from active_gym import shard_game
+    games = ["breakout", "boxing", "pong"]
+    assert [shard_game(games, r) for r in range(8)] == ["breakout", "boxing", "pong", "breakout", "boxing", "pong", "breakout", "boxing"]
+    assert shard_game("seaquest", 5) == "seaquest"
+    with pytest.raises(ValueError):
+        shard_game([], 0)
