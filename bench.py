@@ -45,7 +45,7 @@ def parse():
     ap.add_argument("--no-events", action="store_true", help="skip per-kernel HIP events in the timed region")
     ap.add_argument("--fused", action="store_true",
                     help="fixed kind: use agx_step_fixed's heterogeneous launch (sets AGX_STEP_FUSED=1; measured a tie)")
-    ap.add_argument("--event-every", type=int, default=4,
+    ap.add_argument("--event-every", type=int, default=8,
                     help="bracket the kernels of every M-th timed step with HIP events (each record costs ~2-3 us of "
                          "stream time; M=1 measures every launch)")
     return ap.parse_args()
@@ -268,7 +268,7 @@ def main():
         step(k)
     K = args.steps
     use_ev = not args.no_events
-    M = max(1, args.event_every)
+    M = max(1, min(args.event_every, K // 8))        # at least ~8 bracketed steps however short the run
     ev = {k: [torch.cuda.Event(enable_timing=True) for _ in range(3)] for k in range(0, K, M)} if use_ev else {}
     for e in ev.values():          # create the HIP event handles (the fused call records e[1] through the C ABI)
         for x in e:
