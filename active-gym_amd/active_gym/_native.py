@@ -42,6 +42,7 @@ SIGNATURES = {
     "agx_last_error": (C.c_char_p, [_P]),
     "agx_obs_shape": (C.c_int, [_P, C.POINTER(C.c_int32 * 4)]),
     "agx_algorithmic_bytes": (C.c_int64, [_P, C.c_int]),
+    "agx_profile_next": (C.c_int, [_P, C.c_int, _P, _P]),
     "agx_ingest": (C.c_int, [_P, _P, _P, _P]),
     "agx_ingest_gray": (C.c_int, [_P, _P, _P, _P]),
     "agx_ingest_gray_raw": (C.c_int, [_P, _P, _P, _P]),

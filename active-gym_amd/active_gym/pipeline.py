@@ -131,6 +131,12 @@ class ObsPipeline:
             raise nat.AgxError(int(v), "algorithmic_bytes")
         return int(v)
 
+    def profile_next(self, kernel: str, start: torch.cuda.Event, stop: torch.cuda.Event):
+        """Arm `start` / `stop` (torch.cuda.Event(enable_timing=True), already recorded once so that their handles
+        exist) for the next launch of `kernel` ("ingest" | "fovea"): they receive the kernel's own begin / end."""
+        k = {"ingest": nat.K_INGEST, "fovea": nat.K_FOVEA}[kernel]
+        nat.check(self._lib.agx_profile_next(self._ctx, k, C.c_void_p(start.cuda_event), C.c_void_p(stop.cuda_event)), self._ctx)
+
     # ------------------------------------------------------------------ K1
     def ingest(self, frames: torch.Tensor, cmd: torch.Tensor):
         """frames u8[N,2,210,160,3] RGB, cmd u8[N] (nvalid | CMD_CLEAR | CMD_SKIP)."""

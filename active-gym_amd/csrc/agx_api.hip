@@ -1,6 +1,7 @@
 // agx_api.hip — the C ABI declared in include/agx.h: context, table builders, launches.
 // Built for gfx950 only (see ../build.py): hipcc --offload-arch=gfx950 -shared -fPIC.
 #include <hip/hip_runtime.h>
+#include <hip/hip_ext.h>
 
 #include <cmath>
 #include <cstdarg>
@@ -42,6 +43,7 @@ struct agx_ctx {
     int rows_touched = 0;
     int y_affine = 0, y_mul = 0, y_add = 0, y_shift = 0;   // see IngestParams
     int init_r = 0, init_c = 0;
+    hipEvent_t prof[2][2] = {{nullptr, nullptr}, {nullptr, nullptr}};   // agx_profile_next: [ingest | fovea][start | stop]
     // Tuning / testing knobs, read from the environment ONCE PER CONTEXT in agx_create (so one process can hold
     // contexts of several variants and compare them: tests/test_gpu_parity.py::test_kernel_variants_bit_identical).
     // Every variant is bit-identical to the default; the defaults are the measured-fastest forms.
@@ -56,6 +58,20 @@ struct agx_ctx {
     } tune;
     std::string err;
 };
+
+// Launch of a benchmarked kernel.  When agx_profile_next armed a start / stop event pair for this kernel family the
+// launch goes through hipExtLaunchKernelGGL, which stamps the two events with the dispatch's own begin / end times (the
+// times rocprofv3's kernel trace reports) instead of bracketing it with two more packets on the stream.
+#define AGX_LAUNCH(which, kernel, grid, block, lds, stream, ...)                                              \
+    do {                                                                                                      \
+        hipEvent_t e0_ = ctx->prof[which][0], e1_ = ctx->prof[which][1];                                      \
+        if (e0_ && e1_) {                                                                                     \
+            ctx->prof[which][0] = ctx->prof[which][1] = nullptr;                                              \
+            hipExtLaunchKernelGGL(kernel, grid, block, (uint32_t)(lds), stream, e0_, e1_, 0, __VA_ARGS__);    \
+        } else {                                                                                              \
+            hipLaunchKernelGGL(kernel, grid, block, lds, stream, __VA_ARGS__);                                \
+        }                                                                                                     \
+    } while (0)
 
 namespace {
 
@@ -483,6 +499,17 @@ int agx_obs_shape(const agx_ctx *ctx, int32_t dims[4]) {
     return AGX_OK;
 }
 
+int agx_profile_next(agx_ctx *ctx, int kernel_id, void *start_event, void *stop_event) {
+    if (!ctx) return AGX_E_INVALID;
+    const int which = kernel_id == AGX_K_INGEST ? 0 : (kernel_id == AGX_K_FOVEA ? 1 : -1);
+    if (which < 0) return fail(ctx, AGX_E_INVALID, "agx_profile_next: kernel_id must be AGX_K_INGEST or AGX_K_FOVEA");
+    if ((start_event == nullptr) != (stop_event == nullptr))
+        return fail(ctx, AGX_E_INVALID, "agx_profile_next: pass both events, or neither to disarm");
+    ctx->prof[which][0] = static_cast<hipEvent_t>(start_event);
+    ctx->prof[which][1] = static_cast<hipEvent_t>(stop_event);
+    return AGX_OK;
+}
+
 int64_t agx_algorithmic_bytes(const agx_ctx *ctx, int kernel_id) {
     if (!ctx) return AGX_E_INVALID;
     const agx_config &c = ctx->cfg;
@@ -569,7 +596,7 @@ int agx_ingest(agx_ctx *ctx, const uint8_t *d_frames, const uint8_t *d_cmd, void
     } else if (ctx->ingest_t == 128)
         hipLaunchKernelGGL(k_ingest<128>, dim3(bands, c.num_envs), dim3(128), lds, S(stream), p);
     else
-        hipLaunchKernelGGL(k_ingest<256>, dim3(bands, c.num_envs), dim3(256), lds, S(stream), p);
+        AGX_LAUNCH(0, k_ingest<256>, dim3(bands, c.num_envs), dim3(256), lds, S(stream), p);
     AGX_HIP(ctx, hipGetLastError());
     ctx->cur_head ^= 1;
     return AGX_OK;
@@ -588,7 +615,7 @@ int agx_ingest_gray_raw(agx_ctx *ctx, const uint8_t *d_gray, const uint8_t *d_cm
     p.band_rows = std::min(br, ctx->band_rows > 0 && ctx->ingest_t == 256 ? ctx->band_rows : br);
     p.nbands = (c.obs_h + p.band_rows - 1) / p.band_rows;
     const size_t lds = sizeof(int4) * p.band_rows + sizeof(int2) * c.obs_w + (size_t)2 * p.band_rows * 2 * kRawW;
-    hipLaunchKernelGGL(k_ingest_grayraw, dim3(p.nbands, c.num_envs), dim3(kThreads), lds, S(stream), p);
+    AGX_LAUNCH(0, k_ingest_grayraw, dim3(p.nbands, c.num_envs), dim3(kThreads), lds, S(stream), p);
     AGX_HIP(ctx, hipGetLastError());
     ctx->cur_head ^= 1;
     return AGX_OK;
@@ -637,7 +664,7 @@ int agx_ingest_rgb(agx_ctx *ctx, const uint8_t *d_frames, const uint8_t *d_cmd, 
         default: return fail(ctx, AGX_E_INVALID, "agx_ingest_rgb: unknown gray_mode %d", gray_mode);
     }
     const int words = c.obs_h * c.obs_w / 4;
-    hipLaunchKernelGGL(k_ingest_rgb, dim3((words + kThreads - 1) / kThreads, c.num_envs), dim3(kThreads), 0, S(stream), p);
+    AGX_LAUNCH(0, k_ingest_rgb, dim3((words + kThreads - 1) / kThreads, c.num_envs), dim3(kThreads), 0, S(stream), p);
     AGX_HIP(ctx, hipGetLastError());
     ctx->cur_head ^= 1;
     return AGX_OK;
@@ -785,9 +812,9 @@ int agx_fovea_fixed(agx_ctx *ctx, const void *d_action, int action_dtype, const 
 #define LAUNCH(MODE)                                                                                  \
     do {                                                                                              \
         if (headline)                                                                                 \
-            hipLaunchKernelGGL((k_fovea_fixed<GS, MODE>), grid, block, lds, S(stream), GS{}, p);      \
+            AGX_LAUNCH(1, (k_fovea_fixed<GS, MODE>), grid, block, lds, S(stream), GS{}, p);      \
         else                                                                                          \
-            hipLaunchKernelGGL((k_fovea_fixed<GeomR, MODE>), grid, block, lds, S(stream), gr, p);     \
+            AGX_LAUNCH(1, (k_fovea_fixed<GeomR, MODE>), grid, block, lds, S(stream), gr, p);     \
     } while (0)
     // two physical slots per workgroup (whole launch resident at once, second frame's load hidden): measured a tie
     // with the one-slot form at N=1024 (26.3 vs 25.8 us) - the launch is store-limited - so it is opt-in
@@ -888,12 +915,12 @@ int agx_fovea_peripheral(agx_ctx *ctx, const void *d_action, int action_dtype, c
         const size_t lds = per2_lds(c);
         // both squeeze tables are padded to their own bucket; the kernel bound must not exceed either row pitch
         const bool same_bucket = ctx->per_maxt[0] == ctx->per_maxt[1];
-        if (same_bucket && mt == 2) hipLaunchKernelGGL(k_fovea_peripheral2<2>, grid, block, lds, S(stream), g, p);
-        else if (same_bucket && mt == 4) hipLaunchKernelGGL(k_fovea_peripheral2<4>, grid, block, lds, S(stream), g, p);
-        else if (same_bucket && mt == 8) hipLaunchKernelGGL(k_fovea_peripheral2<8>, grid, block, lds, S(stream), g, p);
-        else if (same_bucket && mt == 12) hipLaunchKernelGGL(k_fovea_peripheral2<12>, grid, block, lds, S(stream), g, p);
-        else if (same_bucket && mt == 16) hipLaunchKernelGGL(k_fovea_peripheral2<16>, grid, block, lds, S(stream), g, p);
-        else hipLaunchKernelGGL(k_fovea_peripheral2<0>, grid, block, lds, S(stream), g, p);
+        if (same_bucket && mt == 2) AGX_LAUNCH(1, k_fovea_peripheral2<2>, grid, block, lds, S(stream), g, p);
+        else if (same_bucket && mt == 4) AGX_LAUNCH(1, k_fovea_peripheral2<4>, grid, block, lds, S(stream), g, p);
+        else if (same_bucket && mt == 8) AGX_LAUNCH(1, k_fovea_peripheral2<8>, grid, block, lds, S(stream), g, p);
+        else if (same_bucket && mt == 12) AGX_LAUNCH(1, k_fovea_peripheral2<12>, grid, block, lds, S(stream), g, p);
+        else if (same_bucket && mt == 16) AGX_LAUNCH(1, k_fovea_peripheral2<16>, grid, block, lds, S(stream), g, p);
+        else AGX_LAUNCH(1, k_fovea_peripheral2<0>, grid, block, lds, S(stream), g, p);
     } else {
         hipLaunchKernelGGL((k_fovea_generic<AGX_KIND_PERIPHERAL>), dim3(c.frame_stack, c.num_envs), dim3(kThreads),
                            generic_lds(c), S(stream), gr, p);
@@ -925,7 +952,7 @@ int agx_fovea_flexible(agx_ctx *ctx, const void *d_action, int action_dtype, con
             fam[k]->meta = ctx->flex_meta[k];
         }
         g.oh = c.obs_h; g.ow = c.obs_w; g.fh = c.fov_h; g.fw = c.fov_w;
-        hipLaunchKernelGGL(k_fovea_flexible2, dim3(c.frame_stack, c.num_envs), dim3(kThreads), lds2, S(stream), g, p);
+        AGX_LAUNCH(1, k_fovea_flexible2, dim3(c.frame_stack, c.num_envs), dim3(kThreads), lds2, S(stream), g, p);
     } else {
         hipLaunchKernelGGL((k_fovea_generic<AGX_KIND_FLEXIBLE>), dim3(c.frame_stack, c.num_envs), dim3(kThreads),
                            generic_lds(c), S(stream), gr, p);

@@ -45,7 +45,11 @@ def parse():
     ap.add_argument("--no-events", action="store_true", help="skip per-kernel HIP events in the timed region")
     ap.add_argument("--fused", action="store_true",
                     help="fixed kind: use agx_step_fixed's heterogeneous launch (sets AGX_STEP_FUSED=1; measured a tie)")
-    ap.add_argument("--event-every", type=int, default=8,
+    ap.add_argument("--event-mode", default="kernel", choices=("kernel", "stream"),
+                    help="kernel: start/stop HIP events stamped by the launch itself (hipExtLaunchKernelGGL through "
+                         "agx_profile_next: the kernel's own begin/end, what rocprofv3 reports); stream: events recorded "
+                         "on the stream before/after each launch (adds the ~2-3 us dispatch gap and slows the stream)")
+    ap.add_argument("--event-every", type=int, default=16,
                     help="bracket the kernels of every M-th timed step with HIP events (each record costs ~2-3 us of "
                          "stream time; M=1 measures every launch)")
     return ap.parse_args()
@@ -245,9 +249,16 @@ def main():
 
     fused = args.kind == "fixed" and args.fused and os.environ.get("AGX_STEP_FUSED") is not None
 
+    kernel_events = args.event_mode == "kernel" and not fused
+
     def step(k, e=None):
-        """One pass of the hot path over batch k of the pool; `e` = 3 HIP events bracketing its two launches."""
+        """One pass of the hot path over batch k of the pool; `e` = the HIP events of a sampled step: 4 stamped by
+        its two launches themselves (kernel mode) or 3 recorded on the stream around them (stream mode)."""
         i = k % args.pool
+        if e is not None and kernel_events:
+            pipe.profile_next("ingest", e[0], e[1])
+            pipe.profile_next("fovea", e[2], e[3])
+            e = None
         if e is not None:
             e[0].record()
         if fused:
@@ -269,7 +280,7 @@ def main():
     K = args.steps
     use_ev = not args.no_events
     M = max(1, min(args.event_every, K // 8))        # at least ~8 bracketed steps however short the run
-    ev = {k: [torch.cuda.Event(enable_timing=True) for _ in range(3)] for k in range(0, K, M)} if use_ev else {}
+    ev = {k: [torch.cuda.Event(enable_timing=True) for _ in range(4 if kernel_events else 3)] for k in range(0, K, M)} if use_ev else {}
     for e in ev.values():          # create the HIP event handles (the fused call records e[1] through the C ABI)
         for x in e:
             x.record()
@@ -293,7 +304,7 @@ def main():
         roof = None
         if use_ev:
             t_ing = sum(e[0].elapsed_time(e[1]) for e in ev.values()) / len(ev) * 1e-3
-            t_fov = sum(e[1].elapsed_time(e[2]) for e in ev.values()) / len(ev) * 1e-3
+            t_fov = sum((e[2].elapsed_time(e[3]) if kernel_events else e[1].elapsed_time(e[2])) for e in ev.values()) / len(ev) * 1e-3
             b_ing, b_fov = pipe.algorithmic_bytes("ingest_gray_raw" if gray else "ingest"), pipe.algorithmic_bytes("fovea")
             if fused:
                 fs = pipe.frame_stack
@@ -308,7 +319,9 @@ def main():
             roof = {"bound": "hbm", "kernel": dom, "achieved": kernels[dom]["achieved_GBps"], "peak": HBM_PEAK_GBS,
                     "unit": "GB/s", "frac": kernels[dom]["frac"], "traffic": None,
                     "avg_launch_us": kernels[dom]["avg_us"], "algorithmic_bytes_per_launch": kernels[dom]["algorithmic_bytes"],
-                    "launches_timed": len(ev), "timing": f"HIP events on the launch stream around every {M}th step of the timed region"}
+                    "launches_timed": len(ev), "timing": (f"HIP start/stop events stamped by the launch itself (hipExtLaunchKernelGGL) on every {M}th step of the "
+                               "timed region, on the launch stream" if kernel_events else
+                               f"HIP events recorded on the launch stream around every {M}th step of the timed region")}
             tr = pmc_traffic(dom, n, args.kind)
             if tr is not None:
                 roof["traffic"] = tr["traffic"]

@@ -150,6 +150,12 @@ AGX_API int agx_ingest_gray_raw(agx_ctx *ctx, const uint8_t *d_gray, const uint8
  * dmc_env.py:175-186, and tests). */
 AGX_API int agx_ingest_gray(agx_ctx *ctx, const uint8_t *d_small, const uint8_t *d_cmd, void *stream);
 
+/* Measurement aid: the NEXT launch of the given kernel family (AGX_K_INGEST: agx_ingest / agx_ingest_gray_raw /
+ * agx_ingest_rgb; AGX_K_FOVEA: agx_fovea_*) stamps `start_event` / `stop_event` (hipEvent_t created with timing) with
+ * the begin / end of that kernel's execution (hipExtLaunchKernelGGL) - the interval rocprofv3's kernel trace reports,
+ * with no extra packets on the stream.  One-shot; pass NULL, NULL to disarm.  The opt-in variant launches ignore it. */
+AGX_API int agx_profile_next(agx_ctx *ctx, int kernel_id, void *start_event, void *stop_event);
+
 /* DMC pixel front end (reference dmc_env.py:175-186,211-234): d_frames u8 [N][obs_h][obs_w][3] are the
  * obs-sized `physics.render()` images (RGB); the reference runs `cv2.cvtColor(obs, cv2.COLOR_BGR2GRAY)` on them,
  * i.e. OpenCV's fixed-point luma with channel 0 weighted as blue, then `/255` and one append per step (no max-pool,

@@ -662,6 +662,41 @@ def test_generic_fallback_kernel_matches_tuned(dev, kind, monkeypatch):
     g.close()
 
 
+def test_profile_next_stamps_kernel_scoped_events(dev):
+    """agx_profile_next: the next launch of a kernel family stamps a start / stop HIP event pair with its own begin /
+    end (hipExtLaunchKernelGGL); one-shot; results unchanged."""
+    N = 256
+    kw = dict(num_envs=N, kind="fixed", obs_size=(84, 84), fov_size=(30, 30), frame_stack=4, resize_to_full=True,
+              fov_init_loc=(0, 0), sensory_action_mode="absolute")
+    a, b = _pipe(**kw), _pipe(**kw)
+    rng = np.random.default_rng(3)
+    frames = _t(rng.integers(0, 256, (N, 2, 210, 160, 3), dtype=np.uint8), dev)
+    cmd = _t(np.full(N, 2, np.uint8), dev)
+    act = _t(rng.uniform(0, 54, (N, 2)).astype(np.float32), dev)
+    ev = [torch.cuda.Event(enable_timing=True) for _ in range(4)]
+    for e in ev:
+        e.record()                       # creates the handles
+    torch.cuda.synchronize()
+    for it in range(3):
+        if it == 1:
+            a.profile_next("ingest", ev[0], ev[1])
+            a.profile_next("fovea", ev[2], ev[3])
+        a.ingest(frames, cmd)
+        oa, la = a.fovea(act)
+        b.ingest(frames, cmd)
+        ob, lb = b.fovea(act)
+        assert torch.equal(oa, ob) and torch.equal(la, lb) and torch.equal(a.stack_u8(), b.stack_u8())
+    torch.cuda.synchronize()
+    t_ing, t_fov = ev[0].elapsed_time(ev[1]), ev[2].elapsed_time(ev[3])
+    assert 0.002 < t_ing < 5.0 and 0.002 < t_fov < 5.0, (t_ing, t_fov)          # ms: a real kernel interval each
+    assert ev[1].elapsed_time(ev[2]) >= 0.0                                      # ingest ended before fovea began
+    from active_gym import _native as nat
+    with pytest.raises(nat.AgxError):
+        nat.check(nat.lib().agx_profile_next(a._ctx, 99, None, None), a._ctx)
+    a.close()
+    b.close()
+
+
 # ---------------------------------------------------------------- streams, several contexts, lifetime
 def test_non_default_stream_and_interleaved_contexts(dev):
     N = 12
