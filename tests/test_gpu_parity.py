@@ -697,6 +697,72 @@ def test_profile_next_stamps_kernel_scoped_events(dev):
     b.close()
 
 
+def test_c_abi_demo_matches_python_binding(dev, tmp_path):
+    """examples/c_abi_demo.cpp drives libagx from plain C++ (hipMalloc buffers, no torch, no Python); the same LCG
+    inputs through the ctypes binding must give the same ring / fov_loc / observation checksums."""
+    import json
+    import shutil
+    import subprocess
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    if not os.path.exists(hipcc):
+        pytest.skip("hipcc not on this box")
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = str(tmp_path / "c_abi_demo")
+    libdir = os.path.join(repo, "active-gym_amd", "lib")
+    subprocess.run([hipcc, "--offload-arch=gfx950", "-O2", "-I", os.path.join(repo, "include"),
+                    os.path.join(repo, "examples", "c_abi_demo.cpp"), "-o", exe, "-L", libdir, "-lagx",
+                    f"-Wl,-rpath,{libdir}"], check=True, timeout=600)
+    N, steps, fs = 24, 4, 4
+    got = json.loads(subprocess.run([exe, str(N), str(steps)], check=True, capture_output=True, text=True, timeout=120)
+                     .stdout.strip().splitlines()[-1])
+
+    def lcg_block(state, count):
+        """count consecutive LCG outputs, vectorised by jumping: x_{k} = A_k x_0 + C_k (mod 2^32)."""
+        A = np.empty(count, np.uint64)
+        Cc = np.empty(count, np.uint64)
+        a, c, m = 1664525, 1013904223, 0xFFFFFFFF
+        # doubling construction of (A_k, C_k)
+        A[0], Cc[0] = a, c
+        n = 1
+        while n < count:
+            k = min(n, count - n)
+            An, Cn = int(A[n - 1]), int(Cc[n - 1])
+            A[n:n + k] = (A[:k] * np.uint64(An)) & np.uint64(m)
+            Cc[n:n + k] = (A[:k] * np.uint64(Cn) + Cc[:k]) & np.uint64(m)
+            n += k
+        out = (A * np.uint64(state) + Cc) & np.uint64(m)
+        return out.astype(np.uint32), int(out[-1])
+
+    p = _pipe(num_envs=N, kind="fixed", obs_size=(84, 84), fov_size=(30, 30), frame_stack=fs, resize_to_full=True,
+              fov_init_loc=(0, 0), sensory_action_mode="absolute")
+    state = 12345
+    nb = N * 2 * 210 * 160 * 3
+    for t in range(steps):
+        r, state = lcg_block(state, nb)
+        frames = (r >> np.uint32(24)).astype(np.uint8).reshape(N, 2, 210, 160, 3)
+        cmd = np.array([(1 | 4) if t == 0 else (1 if i % 7 == 3 else 2) for i in range(N)], np.uint8)
+        r, state = lcg_block(state, 2 * N)
+        act = ((r >> np.uint32(16)).astype(np.float32) * np.float32(65.0 / 65536.0) - np.float32(5.0)).reshape(N, 2)
+        p.ingest(_t(frames, dev), _t(cmd, dev))
+        obs, loc = p.fovea(_t(act, dev))
+    ring = p.stack_u8().cpu().numpy().reshape(-1)
+    obs = obs.cpu().numpy().reshape(-1)
+    loc = loc.cpu().numpy().reshape(-1).astype(np.uint64)
+
+    def fnv(words):
+        h = 1469598103934665603
+        for w in words.tolist():
+            h = ((h ^ w) * 1099511628211) & 0xFFFFFFFFFFFFFFFF
+        return h
+
+    assert got["abi"] == 1 and got["N"] == N and got["steps"] == steps
+    assert got["ring_sum"] == int(ring.astype(np.uint64).sum()) and got["ring_hash"] == fnv(ring)
+    assert got["loc_sum"] == int((loc * np.arange(1, 2 * N + 1, dtype=np.uint64)).sum())
+    assert got["obs_hash"] == fnv(obs.view(np.uint32)), "float observations must agree bit for bit"
+    assert abs(got["obs_sum"] - float(obs.astype(np.float64).sum())) < 1e-6
+    p.close()
+
+
 # ---------------------------------------------------------------- streams, several contexts, lifetime
 def test_non_default_stream_and_interleaved_contexts(dev):
     N = 12
