@@ -106,3 +106,21 @@ def test_ring_oracle_semantics():
     ring.ingest(frames[::-1].copy(), nvalid=[1, 1, 1], clear=[0, 1, 0], skip=[0, 0, 1])
     st2 = ring.stack_u8()
     assert np.array_equal(st2[0, 1], st[0, 2]) and (st2[1, :2] == 0).all() and np.array_equal(st2[2], st[2])
+
+
+def test_cv_resize_within_one_lsb_of_float_bilinear_half_pixel_centres():
+    """Independent cross-check of the restated cv2 INTER_LINEAR geometry (half-pixel centres, edge clamping) against
+    torch's float bilinear with align_corners=False, which samples at the same positions: the 11-bit fixed-point
+    result may differ from the rounded float result by at most 1 LSB, and rarely.  (Pins tap positions / clamping;
+    the exact fixed-point rounding itself stays 'parity unpinned' - cv2 is not in the image.)"""
+    import torch
+    rng = np.random.default_rng(7)
+    for (h, w), (oh, ow) in (((210, 160), (84, 84)), ((210, 160), (64, 64)), ((50, 70), (84, 84)), ((33, 47), (20, 12))):
+        img = rng.integers(0, 256, (h, w), dtype=np.uint8)
+        got = O.cv_resize_linear_u8(img, (ow, oh)).astype(np.int64)
+        ref = torch.nn.functional.interpolate(torch.from_numpy(img.astype(np.float64))[None, None], size=(oh, ow),
+                                              mode="bilinear", align_corners=False)[0, 0].numpy()
+        diff = np.abs(got - np.rint(ref))
+        assert got.shape == (oh, ow) and diff.max() <= 1, (h, w, oh, ow, diff.max())
+        assert (diff > 0).mean() < 0.2                       # the truncating intermediate shifts (>>4, >>16) flip values near .5
+        assert np.abs(got - ref).max() < 1.0
