@@ -280,7 +280,7 @@ size_t generic_lds(const agx_config &c) {
     return (cap + generic_buf1(c)) * sizeof(float) + (size_t)tmax * sizeof(Tap);
 }
 
-constexpr size_t kMaxLds = 64 * 1024;
+constexpr size_t kMaxLds = 160 * 1024;   // gfx950: a workgroup may take the whole 160 KiB of its CU
 
 }  // namespace
 
