@@ -29,12 +29,44 @@ def t(x):
 
 
 def one_case(k):
-    kind = ["fixed", "flexible", "peripheral", "ingest"][k % 4]
+    kind = ["fixed", "flexible", "peripheral", "ingest", "ingest_gray", "ingest_rgb"][k % 6]
     oh = int(rng.integers(3, 33)) * 4
-    ow = oh if kind == "ingest" or rng.random() < 0.5 else int(rng.integers(3, 33)) * 4
+    ow = oh if kind in ("ingest", "ingest_gray") or rng.random() < 0.5 else int(rng.integers(3, 33)) * 4
     fs = int(rng.integers(1, 6))
     N = int(rng.integers(1, 9))
     cfg = dict(kind=kind, obs=(oh, ow), fs=fs, N=N)
+    if kind in ("ingest_gray", "ingest_rgb"):
+        from active_gym import _native as nat
+        p = ObsPipeline(num_envs=N, kind="base", obs_size=(oh, ow), frame_stack=fs, device=dev)
+        ring = np.zeros((N, fs, oh, ow), np.uint8)
+        mode = "cv15" if rng.random() < 0.5 else "cv14"
+        for step in range(3):
+            nvalid = rng.integers(0, 3, N)
+            clear = (rng.random(N) < 0.3).astype(np.uint8)
+            skip = (rng.random(N) < 0.2).astype(np.uint8)
+            nvalid[clear == 1] = 1
+            cmd = (nvalid | clear * 4 | skip * 8).astype(np.uint8)
+            if kind == "ingest_gray":
+                src = rng.integers(0, 256, (N, 2, 210, 160), dtype=np.uint8)
+                p.ingest_gray_raw(t(src), t(cmd))
+            else:
+                src = rng.integers(0, 256, (N, oh, ow, 3), dtype=np.uint8)
+                p.ingest_rgb(t(src), t(cmd), nat.GRAY_CV15 if mode == "cv15" else nat.GRAY_CV14)
+            for i in range(N):
+                if skip[i]:
+                    continue
+                if clear[i]:
+                    ring[i] = 0
+                new = np.zeros((oh, ow), np.uint8)
+                if kind == "ingest_gray":
+                    for f in range(int(nvalid[i])):
+                        new = np.maximum(new, O.cv_resize_linear_u8(src[i, f], (ow, oh)))
+                elif nvalid[i]:
+                    new = O.cv_bgr2gray_u8(src[i], mode)
+                ring[i] = np.concatenate([ring[i, 1:], new[None]], 0)
+            assert np.array_equal(p.stack_u8().cpu().numpy(), ring), cfg
+        p.close()
+        return cfg
     if kind == "ingest":
         p = ObsPipeline(num_envs=N, kind="base", obs_size=(oh, ow), frame_stack=fs, device=dev)
         ring = O.RingOracle(N, fs, (oh, ow))
