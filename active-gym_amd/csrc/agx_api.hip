@@ -336,8 +336,11 @@ int agx_create(const agx_config *cfg, agx_ctx **out) {
             return fail(nullptr, AGX_E_INVALID, "fov_init_loc must be finite");
         if (c.kind == AGX_KIND_PERIPHERAL && (c.per_h < 1 || c.per_w < 1 || c.per_h > 1024 || c.per_w > 1024))
             return fail(nullptr, AGX_E_INVALID, "peripheral_res (%d,%d) out of range", c.per_h, c.per_w);
+        // the LDS of the kernel that will actually run: the tuned peripheral kernel when its plan fits (and the
+        // testing knob does not force the fallback), otherwise the generic one
+        const bool per_tuned = env_int("AGX_FOVEA_GENERIC") == 0 && per2_lds(c) <= kMaxLds && c.per_w <= kThreads;
         const size_t lds = c.kind == AGX_KIND_FIXED ? fixed_lds(c)
-                           : (c.kind == AGX_KIND_PERIPHERAL ? std::min(per2_lds(c), generic_lds(c)) : generic_lds(c));
+                           : (c.kind == AGX_KIND_PERIPHERAL && per_tuned ? per2_lds(c) : generic_lds(c));
         if (lds > kMaxLds)
             return fail(nullptr, AGX_E_INVALID, "geometry needs %zu B of LDS per workgroup (limit %zu)", lds, kMaxLds);
     }

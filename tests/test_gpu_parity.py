@@ -662,6 +662,35 @@ def test_generic_fallback_kernel_matches_tuned(dev, kind, monkeypatch):
     g.close()
 
 
+@pytest.mark.parametrize("generic", [False, True])
+def test_large_geometries_are_refused_at_create_or_run(dev, generic, monkeypatch):
+    """Found by tools/fuzz_gpu.py: agx_create must size the LDS of the kernel that will actually run (tuned or generic
+    fallback), so that a geometry is either refused there with a message or launches - never an 'invalid argument' at
+    the first fovea call."""
+    from active_gym import _native as nat
+    if generic:
+        monkeypatch.setenv("AGX_FOVEA_GENERIC", "1")
+    else:
+        monkeypatch.delenv("AGX_FOVEA_GENERIC", raising=False)
+    rng = np.random.default_rng(5)
+    built = refused = 0
+    for obs, fov, per in (((128, 128), (64, 64), (100, 100)), ((128, 128), (100, 90), (127, 127)), ((124, 128), (20, 30), (300, 60)),
+                          ((96, 96), (40, 40), (50, 50)), ((256, 256), (64, 64), (32, 32))):
+        try:
+            p = _pipe(num_envs=3, kind="peripheral", obs_size=obs, fov_size=fov, fov_init_loc=(0, 0), frame_stack=2,
+                      sensory_action_mode="absolute", resize_to_full=True, peripheral_res=per)
+        except nat.AgxError as e:
+            assert "LDS" in str(e) or "peripheral_res" in str(e)
+            refused += 1
+            continue
+        p.set_stack_u8(_t(rng.integers(0, 256, (3, 2) + obs, dtype=np.uint8), dev))
+        o, loc = p.fovea(_t(rng.uniform(0, 60, (3, 2)).astype(np.float32), dev))
+        assert torch.isfinite(o).all()
+        built += 1
+        p.close()
+    assert built >= 1 and refused >= 1
+
+
 def test_profile_next_stamps_kernel_scoped_events(dev):
     """agx_profile_next: the next launch of a kernel family stamps a start / stop HIP event pair with its own begin /
     end (hipExtLaunchKernelGGL); one-shot; results unchanged."""
