@@ -424,12 +424,24 @@ __global__ __launch_bounds__(kThreads) void k_fovea_peripheral2(PerParams g, Fov
         if (!all_fov) {
             const int2 ln = ln3_s[row];
             const float *w = w3_s + row * mt3;
-            for (int k = 0; k < ln.y; ++k) {
-                const float4 v = C4[(ln.x + k) * ow4 + x4];
-                o.x = fmaf(w[k], v.x, o.x);
-                o.y = fmaf(w[k], v.y, o.y);
-                o.z = fmaf(w[k], v.z, o.z);
-                o.w = fmaf(w[k], v.w, o.w);
+            if (mt3 <= 2) {
+                // the expansion is an up-scale (peripheral_res <= obs): one or two taps; unrolled with a zero second
+                // weight (the table is zero-padded to mt3), no per-lane trip count
+                const float w0 = w[0], w1 = mt3 > 1 ? w[1] : 0.f;
+                const float4 v0 = C4[ln.x * ow4 + x4];
+                const float4 v1 = C4[(ln.y > 1 ? ln.x + 1 : ln.x) * ow4 + x4];
+                o.x = fmaf(w1, v1.x, fmaf(w0, v0.x, o.x));
+                o.y = fmaf(w1, v1.y, fmaf(w0, v0.y, o.y));
+                o.z = fmaf(w1, v1.z, fmaf(w0, v0.z, o.z));
+                o.w = fmaf(w1, v1.w, fmaf(w0, v0.w, o.w));
+            } else {
+                for (int k = 0; k < ln.y; ++k) {
+                    const float4 v = C4[(ln.x + k) * ow4 + x4];
+                    o.x = fmaf(w[k], v.x, o.x);
+                    o.y = fmaf(w[k], v.y, o.y);
+                    o.z = fmaf(w[k], v.z, o.z);
+                    o.w = fmaf(w[k], v.w, o.w);
+                }
             }
         }
         if (g.same || (in_r && x + 3 >= c && x < c + fw)) {
