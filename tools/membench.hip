@@ -111,6 +111,20 @@ int main(int argc, char** argv) {
   const int N=1024, POOL=8; const size_t bytes=(size_t)N*2*FRAMEB;
   std::vector<uint8_t*> bufs(POOL); uint32_t* out; CK(hipMalloc(&out, 4096));
   for (auto& b: bufs) { CK(hipMalloc(&b, bytes)); CK(hipMemset(b, 0x5a, bytes)); }
+  if (argc > 1 && argv[1][0] == 's') {
+    // sweep mode: the K1 load shape (k_x3) and the K2 store shape (k_st) at N = 256 ... 4096 envs: slope = streaming rate,
+    // intercept = what a launch of that shape costs before / after it streams
+    float4* ob; CK(hipMalloc(&ob, (size_t)4096*4*1764*16));
+    std::vector<uint8_t*> big(2); for (auto& b: big) { CK(hipMalloc(&b, (size_t)4096*2*FRAMEB)); CK(hipMemset(b, 0x5a, (size_t)4096*2*FRAMEB)); }
+    hipEvent_t e0,e1; hipEventCreate(&e0); hipEventCreate(&e1);
+    for (int n = 256; n <= 4096; n *= 2) {
+      float tl=0, ts=0; const int R=30;
+      for (int r=-5;r<R;++r){ hipEventRecord(e0); hipLaunchKernelGGL(k_x3, dim3(7,n), dim3(256), 0, 0, big[r&1], out); hipEventRecord(e1); hipEventSynchronize(e1); float ms; hipEventElapsedTime(&ms,e0,e1); if(r>=0) tl+=ms; }
+      for (int r=-5;r<R;++r){ hipEventRecord(e0); hipLaunchKernelGGL(k_st, dim3(4,n), dim3(256), 0, 0, ob, (float)r, 1); hipEventRecord(e1); hipEventSynchronize(e1); float ms; hipEventElapsedTime(&ms,e0,e1); if(r>=0) ts+=ms; }
+      printf("N=%4d  x3 loads %.2f us   float4 nt stores %.2f us\n", n, tl/R*1e3, ts/R*1e3);
+    }
+    return 0;
+  }
   if (argc > 1 && argv[1][0] == 'c') {
     // calibration mode for `rocprofv3 --pmc FETCH_SIZE|WRITE_SIZE -- tools/membench cal`: a few launches of each
     // known-byte-count kernel over a 1.65 GB pool (past the 256 MiB Infinity Cache), nothing else
