@@ -55,6 +55,7 @@ struct agx_ctx {
         int pair = 0;            // AGX_FOVEA_PAIR        two ring slots per K2 workgroup
         int fused = 0;           // AGX_STEP_FUSED        agx_step_fixed as one heterogeneous launch + tail
         int generic = 0;         // AGX_FOVEA_GENERIC     K3 / K4 through the generic fallback kernel
+        int no_full = 0;         // AGX_INGEST_NO_FULL    general k_ingest<256> even where k_ingest_full12 applies
     } tune;
     std::string err;
 };
@@ -359,6 +360,7 @@ int agx_create(const agx_config *cfg, agx_ctx **out) {
     ctx->tune.pair = env_int("AGX_FOVEA_PAIR");
     ctx->tune.fused = env_int("AGX_STEP_FUSED");
     ctx->tune.generic = env_int("AGX_FOVEA_GENERIC");
+    ctx->tune.no_full = env_int("AGX_INGEST_NO_FULL");
     DeviceGuard g(c.device);
     int rc = AGX_OK;
     auto bail = [&](int code) {
@@ -598,6 +600,8 @@ int agx_ingest(agx_ctx *ctx, const uint8_t *d_frames, const uint8_t *d_cmd, void
         hipLaunchKernelGGL(k_ingest_pipe<256>, dim3(parts, c.num_envs), dim3(256), lds2, S(stream), p);
     } else if (ctx->ingest_t == 128)
         hipLaunchKernelGGL(k_ingest<128>, dim3(bands, c.num_envs), dim3(128), lds, S(stream), p);
+    else if (ctx->tune.no_full == 0 && ctx->y_affine && ctx->band_rows == 12 && c.obs_h % 12 == 0)
+        AGX_LAUNCH(0, k_ingest_full12, dim3(bands, c.num_envs), dim3(256), lds, S(stream), p);
     else
         AGX_LAUNCH(0, k_ingest<256>, dim3(bands, c.num_envs), dim3(256), lds, S(stream), p);
     AGX_HIP(ctx, hipGetLastError());

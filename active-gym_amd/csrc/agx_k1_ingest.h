@@ -82,20 +82,23 @@ struct IngestParams {
 // Measured floor of this access shape with no arithmetic at all: ~30 us at N=1024 (tools/membench.hip).
 // GRAY: the source frames are already ALE's own grayscale screens, u8 [N][2][210][160] (`getScreenGrayscale`, what the
 // reference itself reads, atari_env.py:74): one dword = 4 pixels per lane, no luminance arithmetic, a third of the bytes.
-template <int T, bool GRAY = false>
+// FBR > 0: compile-time band height with every band full (oh % FBR == 0, 2 * FBR == (T / 40) * 4) and the affine source
+// row form: the row job of iteration `it` is (frame it / 2, row rg + RG * (it % 2)) with no clamping against a ragged
+// last band, so the second frame's offsets are the first's plus a constant and the index arithmetic folds away.
+template <int T, bool GRAY = false, int FBR = 0>
 __device__ __forceinline__ void ingest_band(const IngestParams &p, const int band, const int n, unsigned char *smem) {
     const int tid = threadIdx.x;
     AGX_STAMP(0);
     constexpr uint32_t kRowB = GRAY ? kRawW : kRawRowBytes;               // source row / frame pitch in bytes
     constexpr uint32_t kFrameB = kRawH * kRowB;
-    const int BR = p.band_rows;
+    const int BR = FBR > 0 ? FBR : p.band_rows;
     const int dy0 = band * BR;
-    const int rows = min(BR, p.oh - dy0);
+    const int rows = FBR > 0 ? FBR : min(BR, p.oh - dy0);
     int4 *ytab_s = reinterpret_cast<int4 *>(smem);                      // [BR]
     int2 *xtab_s = reinterpret_cast<int2 *>(smem + sizeof(int4) * BR);    // [ow]
     unsigned char *gray = smem + sizeof(int4) * BR + sizeof(int2) * p.ow; // [2][BR][160][2]
     const int ow4 = p.ow >> 2;
-    if (!p.y_affine) {                       // general geometry: source rows come from the table
+    if (FBR == 0 && !p.y_affine) {           // general geometry: source rows come from the table
         if (tid < rows) ytab_s[tid] = p.ytab[dy0 + tid];
         __syncthreads();
     }
@@ -114,6 +117,18 @@ __device__ __forceinline__ void ingest_band(const IngestParams &p, const int ban
     const uint32_t col = g4 * (GRAY ? 4 : 12);
     int nvalid = 2;                                                       // speculative until cmd arrives
     auto row_offsets = [&](int it, uint32_t &o0, uint32_t &o1, int &d) {
+        if (FBR > 0) {
+            constexpr int half = kIter / 2;
+            const int f = it / half;                                      // compile-time in the unrolled loops
+            const int dyl = min(rg + RG * (it - f * half), FBR - 1);      // (idle threads rg >= RG stay in bounds)
+            const int y0 = (int)(mul_u24((uint32_t)(dy0 + dyl), (uint32_t)p.y_mul) + (uint32_t)p.y_add) >> p.y_shift;
+            const int y1 = min(y0 + 1, kRawH - 1);
+            const uint32_t fo = f * kFrameB + col;
+            o0 = mad_u24((uint32_t)y0, kRowB, fo);
+            o1 = mad_u24((uint32_t)y1, kRowB, fo);
+            d = (f < nvalid && rg < RG) ? ((f * FBR + dyl) * kRawW + g4 * 4) * 2 : -1;
+            return;
+        }
         const int nrj = max(nvalid, 1) * rows;
         const int rj_raw = rg + RG * it;
         const int rj = min(rj_raw, nrj - 1);
@@ -159,7 +174,7 @@ __device__ __forceinline__ void ingest_band(const IngestParams &p, const int ban
     if (nrj > 0) {
 #pragma unroll
         for (int it = 0; it < kIter; ++it)                                // frame-1 jobs are void when nvalid == 1
-            if (rg + RG * it >= nrj) dst[it] = -1;
+            if (FBR > 0 ? (it / (kIter / 2) >= nvalid) : (rg + RG * it >= nrj)) dst[it] = -1;
         AGX_STAMP(1);
         // the phase-2 tables are requested AFTER the frame pieces (vmcnt retires in order, so waiting
         // for them later costs nothing) and parked in LDS once the luminance work is done
@@ -258,6 +273,12 @@ template <int T>
 __global__ __launch_bounds__(T) void k_ingest(IngestParams p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     ingest_band<T>(p, blockIdx.x, blockIdx.y, smem);
+}
+
+// the headline geometry's form: 12-row bands, all full (84 = 7 * 12), affine source rows
+__global__ __launch_bounds__(kThreads) void k_ingest_full12(IngestParams p) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    ingest_band<kThreads, false, 12>(p, blockIdx.x, blockIdx.y, smem);
 }
 
 // K1g: the same from ALE grayscale screens u8 [N][2][210][160] (agx_ingest_gray_raw)
