@@ -41,6 +41,26 @@ __device__ __forceinline__ uint32_t lum4(uint32_t a, uint32_t b, uint32_t c, boo
     return q0 | (q1 << 8) | (q2 << 16) | (q3 << 24);
 }
 
+// The same with a cheaper tie test for the default kernel: the remainder r = t - 10000 q comes from ONE signed 24-bit
+// multiply-add (v_mad_i32_i24), the remainders of a piece are folded with v_min3_u32, and a single compare per row job
+// asks whether any of them is 0 - instead of a multiply, a compare and a scalar OR per pixel.
+__device__ __forceinline__ uint32_t ale_lum_px_r(uint32_t px, uint32_t &rmin) {
+    const uint32_t hi = __builtin_amdgcn_udot4(px, kLumWHi, 0u, false);
+    const uint32_t t = __builtin_amdgcn_udot4(px, kLumWLo, (hi << 8) + 5000u, false);
+    const uint32_t q = (uint32_t)(((uint64_t)(t & 0xFFFFFFu) * 13743896ull) >> 32) >> 5;
+    uint32_t r;
+    asm("v_mad_i32_i24 %0, %1, %2, %3" : "=v"(r) : "v"(q), "s"(-10000), "v"(t));     // 0 <= r < 10000
+    rmin = min(rmin, r);
+    return q;
+}
+__device__ __forceinline__ uint32_t lum4_r(uint32_t a, uint32_t b, uint32_t c, uint32_t &rmin) {
+    const uint32_t q0 = ale_lum_px_r(a, rmin);
+    const uint32_t q1 = ale_lum_px_r(__builtin_amdgcn_alignbyte(b, a, 3), rmin);
+    const uint32_t q2 = ale_lum_px_r(__builtin_amdgcn_alignbyte(c, b, 2), rmin);
+    const uint32_t q3 = ale_lum_px_r(c >> 8, rmin);
+    return q0 | (q1 << 8) | (q2 << 16) | (q3 << 24);
+}
+
 // exact-tie replay of one pixel in C double, ALE's operation order, no fused multiply-add
 __device__ __forceinline__ uint32_t ale_lum_exact(uint32_t r, uint32_t g, uint32_t b) {
     const uint32_t t = 2989u * r + 5870u * g + 1140u * b + 5000u;
@@ -183,9 +203,10 @@ __device__ __forceinline__ void ingest_band(const IngestParams &p, const int ban
         uint32_t tie_its = 0;
 #pragma unroll
         for (int it = 0; it < kIter; ++it) {
-            bool tie = false;
-            const uint32_t top = GRAY ? w0[it].x : lum4(w0[it].x, w0[it].y, w0[it].z, tie);
-            const uint32_t bot = GRAY ? w1[it].x : lum4(w1[it].x, w1[it].y, w1[it].z, tie);
+            uint32_t rmin = 1u;                                           // smallest remainder of the 8 pixels (GRAY: none)
+            const uint32_t top = GRAY ? w0[it].x : lum4_r(w0[it].x, w0[it].y, w0[it].z, rmin);
+            const uint32_t bot = GRAY ? w1[it].x : lum4_r(w1[it].x, w1[it].y, w1[it].z, rmin);
+            const bool tie = rmin == 0u;
             if (dst[it] >= 0) {
                 uint2 v;                                                  // t0 b0 t1 b1 | t2 b2 t3 b3
                 v.x = __builtin_amdgcn_perm(bot, top, 0x05010400u);
