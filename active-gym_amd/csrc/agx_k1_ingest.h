@@ -249,7 +249,7 @@ __device__ __forceinline__ void ingest_band(const IngestParams &p, const int ban
 
     // phase 2: OpenCV fixed-point bilinear + max over the sampled frames
     if (tid < rows * ow4) {
-        const int dyl = tid / ow4, xq = tid - dyl * ow4;
+        const int dyl = FastDiv(ow4).div(tid), xq = tid - dyl * ow4;
         const int dy = dy0 + dyl;
         uint32_t b0 = 0, b1 = 0;
         int4 xt01 = make_int4(0, 0, 0, 0), xt23 = xt01;
@@ -260,25 +260,35 @@ __device__ __forceinline__ void ingest_band(const IngestParams &p, const int ban
             xt01 = *reinterpret_cast<const int4 *>(xtab_s + xq * 4);
             xt23 = *reinterpret_cast<const int4 *>(xtab_s + xq * 4 + 2);
         }
-        uint32_t packed = 0;
         const int xi[4] = {xt01.x, xt01.z, xt23.x, xt23.z};
         const int xa[4] = {xt01.y, xt01.w, xt23.y, xt23.w};
         const unsigned char *row0 = gray + mul_u24((uint32_t)dyl, kRawW * 2);      // frame 0, this output row
         const uint32_t fstride = (uint32_t)BR * kRawW * 2;                         // wave-uniform
+        // both frames' taps are read up front (16 ds_read_u16 in flight, no per-frame loop); a frame that was not
+        // sampled this step is masked out of the max afterwards - its LDS bytes are stale but never used
+        uint32_t pp[4][2][2];
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+#pragma unroll
+            for (int f = 0; f < 2; ++f) {
+                const uint16_t *row = reinterpret_cast<const uint16_t *>(row0 + f * fstride);
+                pp[k][f][0] = row[xi[k] & 0xFFFF];                                 // lo byte: row y0, hi byte: row y1
+                pp[k][f][1] = row[(uint32_t)xi[k] >> 16];
+            }
+        const uint32_t keep0 = nvalid > 0 ? 0xFFu : 0u, keep1 = nvalid > 1 ? 0xFFu : 0u;
+        uint32_t packed = 0;
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
-            const uint32_t x0 = xi[k] & 0xFFFF, x1 = (uint32_t)xi[k] >> 16;
             const uint32_t a0 = xa[k] & 0xFFFF, a1 = (uint32_t)xa[k] >> 16;
-            uint32_t best = 0;
-            for (int f = 0; f < nvalid; ++f) {
-                const uint16_t *row = reinterpret_cast<const uint16_t *>(row0 + f * fstride);
-                const uint32_t p0 = row[x0], p1 = row[x1];               // lo byte: row y0, hi byte: row y1
+            uint32_t v[2];
+#pragma unroll
+            for (int f = 0; f < 2; ++f) {
+                const uint32_t p0 = pp[k][f][0], p1 = pp[k][f][1];
                 const uint32_t h0 = mad_u24(p1 & 0xFF, a1, mul_u24(p0 & 0xFF, a0));
                 const uint32_t h1 = mad_u24(p1 >> 8, a1, mul_u24(p0 >> 8, a0));
-                const uint32_t v = (((mul_u24(b0, h0 >> 4) >> 16) + (mul_u24(b1, h1 >> 4) >> 16) + 2) >> 2) & 0xFF;
-                best = max(best, v);
+                v[f] = ((mul_u24(b0, h0 >> 4) >> 16) + (mul_u24(b1, h1 >> 4) >> 16) + 2) >> 2;
             }
-            packed |= best << (8 * k);
+            packed |= max(v[0] & keep0, v[1] & keep1) << (8 * k);
         }
         const uint32_t fsz = (uint32_t)p.oh * p.ow;
         uint8_t *env = p.ring + (size_t)n * p.fs * fsz;                            // wave-uniform
