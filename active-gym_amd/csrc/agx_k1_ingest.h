@@ -279,13 +279,18 @@ __device__ __forceinline__ void ingest_band(const IngestParams &p, const int ban
         uint32_t packed = 0;
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
-            const uint32_t a0 = xa[k] & 0xFFFF, a1 = (uint32_t)xa[k] >> 16;
+            // horizontal pass as two v_dot2_u32_u16: the table already stores the coefficient pair as a0 | a1 << 16, and
+            // one v_perm_b32 puts the two taps of a source row side by side as 16-bit lanes
+            typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
+            const u16x2 aa = __builtin_bit_cast(u16x2, (uint32_t)xa[k]);
             uint32_t v[2];
 #pragma unroll
             for (int f = 0; f < 2; ++f) {
                 const uint32_t p0 = pp[k][f][0], p1 = pp[k][f][1];
-                const uint32_t h0 = mad_u24(p1 & 0xFF, a1, mul_u24(p0 & 0xFF, a0));
-                const uint32_t h1 = mad_u24(p1 >> 8, a1, mul_u24(p0 >> 8, a0));
+                const uint32_t top = __builtin_amdgcn_perm(p1, p0, 0x0C040C00u);   // p0.byte0 | p1.byte0 << 16  (row y0)
+                const uint32_t bot = __builtin_amdgcn_perm(p1, p0, 0x0C050C01u);   // p0.byte1 | p1.byte1 << 16  (row y1)
+                const uint32_t h0 = __builtin_amdgcn_udot2(__builtin_bit_cast(u16x2, top), aa, 0u, false);
+                const uint32_t h1 = __builtin_amdgcn_udot2(__builtin_bit_cast(u16x2, bot), aa, 0u, false);
                 v[f] = ((mul_u24(b0, h0 >> 4) >> 16) + (mul_u24(b1, h1 >> 4) >> 16) + 2) >> 2;
             }
             packed |= max(v[0] & keep0, v[1] & keep1) << (8 * k);
