@@ -43,7 +43,9 @@ res["factors"] = {"fetch_16B_lane": f16, "fetch_12B_lane": f12, "write_16B_lane"
 for k, d in collect("bench").items():
     if "agx::" not in k:
         continue
-    short = k.split("agx::")[1].split("<")[0]
+    short = k.split("agx::")[1].split("<")[0].split("(")[0]
+    if short.startswith("k_ingest"):                    # k_ingest<256>, k_ingest_full12: one family, one key
+        short = "k_ingest"
     ff = f12 if short == "k_ingest" else f16            # K1 loads 12 B per lane; K2-K4 read the ring in dwords/x4
     e = {"FETCH_SIZE_raw": d.get("FETCH_SIZE"), "WRITE_SIZE_raw": d.get("WRITE_SIZE"), "fetch_factor_used": ff}
     if ff and "FETCH_SIZE" in d and "WRITE_SIZE" in d:
