@@ -622,7 +622,10 @@ int agx_ingest_gray_raw(agx_ctx *ctx, const uint8_t *d_gray, const uint8_t *d_cm
     p.band_rows = std::min(br, ctx->band_rows > 0 && ctx->ingest_t == 256 ? ctx->band_rows : br);
     p.nbands = (c.obs_h + p.band_rows - 1) / p.band_rows;
     const size_t lds = sizeof(int4) * p.band_rows + sizeof(int2) * c.obs_w + (size_t)2 * p.band_rows * 2 * kRawW;
-    AGX_LAUNCH(0, k_ingest_grayraw, dim3(p.nbands, c.num_envs), dim3(kThreads), lds, S(stream), p);
+    if (ctx->tune.no_full == 0 && ctx->y_affine && p.band_rows == 12 && c.obs_h % 12 == 0)
+        AGX_LAUNCH(0, k_ingest_grayraw_full12, dim3(p.nbands, c.num_envs), dim3(kThreads), lds, S(stream), p);
+    else
+        AGX_LAUNCH(0, k_ingest_grayraw, dim3(p.nbands, c.num_envs), dim3(kThreads), lds, S(stream), p);
     AGX_HIP(ctx, hipGetLastError());
     ctx->cur_head ^= 1;
     return AGX_OK;

@@ -322,6 +322,10 @@ __global__ __launch_bounds__(kThreads) void k_ingest_grayraw(IngestParams p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     ingest_band<kThreads, true>(p, blockIdx.x, blockIdx.y, smem);
 }
+__global__ __launch_bounds__(kThreads) void k_ingest_grayraw_full12(IngestParams p) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    ingest_band<kThreads, true, 12>(p, blockIdx.x, blockIdx.y, smem);
+}
 
 // ---------------------------------------------------------------------------------------------
 // K1, wave-private form (opt-in, AGX_INGEST_WAVE=1): grid = (bands, N), block = 256, but
