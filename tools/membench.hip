@@ -118,10 +118,14 @@ int main(int argc, char** argv) {
     std::vector<uint8_t*> big(2); for (auto& b: big) { CK(hipMalloc(&b, (size_t)4096*2*FRAMEB)); CK(hipMemset(b, 0x5a, (size_t)4096*2*FRAMEB)); }
     hipEvent_t e0,e1; hipEventCreate(&e0); hipEventCreate(&e1);
     for (int n = 256; n <= 4096; n *= 2) {
-      float tl=0, ts=0; const int R=30;
-      for (int r=-5;r<R;++r){ hipEventRecord(e0); hipLaunchKernelGGL(k_x3, dim3(7,n), dim3(256), 0, 0, big[r&1], out); hipEventRecord(e1); hipEventSynchronize(e1); float ms; hipEventElapsedTime(&ms,e0,e1); if(r>=0) tl+=ms; }
-      for (int r=-5;r<R;++r){ hipEventRecord(e0); hipLaunchKernelGGL(k_st, dim3(4,n), dim3(256), 0, 0, ob, (float)r, 1); hipEventRecord(e1); hipEventSynchronize(e1); float ms; hipEventElapsedTime(&ms,e0,e1); if(r>=0) ts+=ms; }
-      printf("N=%4d  x3 loads %.2f us   float4 nt stores %.2f us\n", n, tl/R*1e3, ts/R*1e3);
+      // back-to-back launches, one event pair around the LAST 100 of 400: sustained clocks (the shader clock steps down
+      // after ~3 ms of load), no per-launch event overhead
+      float tl=0, ts=0; const int W=300, R=100;
+      for (int r=0;r<W;++r) hipLaunchKernelGGL(k_x3, dim3(7,n), dim3(256), 0, 0, big[r&1], out);
+      hipEventRecord(e0); for (int r=0;r<R;++r) hipLaunchKernelGGL(k_x3, dim3(7,n), dim3(256), 0, 0, big[r&1], out); hipEventRecord(e1); hipEventSynchronize(e1); hipEventElapsedTime(&tl,e0,e1);
+      for (int r=0;r<W;++r) hipLaunchKernelGGL(k_st, dim3(4,n), dim3(256), 0, 0, ob, (float)r, 1);
+      hipEventRecord(e0); for (int r=0;r<R;++r) hipLaunchKernelGGL(k_st, dim3(4,n), dim3(256), 0, 0, ob, (float)r, 1); hipEventRecord(e1); hipEventSynchronize(e1); hipEventElapsedTime(&ts,e0,e1);
+      printf("N=%4d  x3 loads %.2f us   float4 nt stores %.2f us   (per launch incl. the ~2 us dispatch gap, sustained)\n", n, tl/R*1e3, ts/R*1e3);
     }
     return 0;
   }
