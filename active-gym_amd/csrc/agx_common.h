@@ -59,6 +59,12 @@ __device__ __forceinline__ uint32_t mul_u24(uint32_t a, uint32_t b) {
     asm("v_mul_u32_u24_e32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
     return r;
 }
+// (a[23:0] * b[23:0]) >> 32
+__device__ __forceinline__ uint32_t mul_hi_u24(uint32_t a, uint32_t b) {
+    uint32_t r;
+    asm("v_mul_hi_u32_u24 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
 __device__ __forceinline__ uint32_t mad_u24(uint32_t a, uint32_t b, uint32_t c) {
     uint32_t r;
     asm("v_mad_u32_u24 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));

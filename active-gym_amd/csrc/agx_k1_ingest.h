@@ -44,9 +44,10 @@ __device__ __forceinline__ uint32_t lum4(uint32_t a, uint32_t b, uint32_t c, boo
 // The same with a cheaper tie test for the default kernel: the remainder r = t - 10000 q comes from ONE signed 24-bit
 // multiply-add (v_mad_i32_i24), the remainders of a piece are folded with v_min3_u32, and a single compare per row job
 // asks whether any of them is 0 - instead of a multiply, a compare and a scalar OR per pixel.
+template <int SH = 0>      // SH = 1: the pixel sits in bytes 1..3 of `px` (weights moved up a byte, no data shift)
 __device__ __forceinline__ uint32_t ale_lum_px_r(uint32_t px, uint32_t &rmin) {
-    const uint32_t hi = __builtin_amdgcn_udot4(px, kLumWHi, 0u, false);
-    const uint32_t t = __builtin_amdgcn_udot4(px, kLumWLo, (hi << 8) + 5000u, false);
+    const uint32_t hi = __builtin_amdgcn_udot4(px, kLumWHi << (8 * SH), 0u, false);
+    const uint32_t t = __builtin_amdgcn_udot4(px, kLumWLo << (8 * SH), (hi << 8) + 5000u, false);
     const uint32_t q = (uint32_t)(((uint64_t)(t & 0xFFFFFFu) * 13743896ull) >> 32) >> 5;
     uint32_t r;
     asm("v_mad_i32_i24 %0, %1, %2, %3" : "=v"(r) : "v"(q), "s"(-10000), "v"(t));     // 0 <= r < 10000
@@ -57,7 +58,7 @@ __device__ __forceinline__ uint32_t lum4_r(uint32_t a, uint32_t b, uint32_t c, u
     const uint32_t q0 = ale_lum_px_r(a, rmin);
     const uint32_t q1 = ale_lum_px_r(__builtin_amdgcn_alignbyte(b, a, 3), rmin);
     const uint32_t q2 = ale_lum_px_r(__builtin_amdgcn_alignbyte(c, b, 2), rmin);
-    const uint32_t q3 = ale_lum_px_r(c >> 8, rmin);
+    const uint32_t q3 = ale_lum_px_r<1>(c, rmin);
     return q0 | (q1 << 8) | (q2 << 16) | (q3 << 24);
 }
 
@@ -276,13 +277,16 @@ __device__ __forceinline__ void ingest_band(const IngestParams &p, const int ban
                 pp[k][f][1] = row[(uint32_t)xi[k] >> 16];
             }
         const uint32_t keep0 = nvalid > 0 ? 0xFFu : 0u, keep1 = nvalid > 1 ? 0xFFu : 0u;
+        const uint32_t b0s = b0 << 8, b1s = b1 << 8;
         uint32_t packed = 0;
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
             // horizontal pass as two v_dot2_u32_u16: the table already stores the coefficient pair as a0 | a1 << 16, and
             // one v_perm_b32 puts the two taps of a source row side by side as 16-bit lanes
             typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
-            const u16x2 aa = __builtin_bit_cast(u16x2, (uint32_t)xa[k]);
+            // coefficients * 16 (a <= 2048 keeps each half inside its 16 bits): the dot2 then yields h << 4, so that
+            // (h >> 4) << 8 is one AND and (b * (h >> 4)) >> 16 one v_mul_hi_u32_u24 of (b << 8) and that value
+            const u16x2 aa = __builtin_bit_cast(u16x2, (uint32_t)xa[k] << 4);
             uint32_t v[2];
 #pragma unroll
             for (int f = 0; f < 2; ++f) {
@@ -291,7 +295,7 @@ __device__ __forceinline__ void ingest_band(const IngestParams &p, const int ban
                 const uint32_t bot = __builtin_amdgcn_perm(p1, p0, 0x0C050C01u);   // p0.byte1 | p1.byte1 << 16  (row y1)
                 const uint32_t h0 = __builtin_amdgcn_udot2(__builtin_bit_cast(u16x2, top), aa, 0u, false);
                 const uint32_t h1 = __builtin_amdgcn_udot2(__builtin_bit_cast(u16x2, bot), aa, 0u, false);
-                v[f] = ((mul_u24(b0, h0 >> 4) >> 16) + (mul_u24(b1, h1 >> 4) >> 16) + 2) >> 2;
+                v[f] = (mul_hi_u24(b0s, h0 & 0xFFFFFF00u) + mul_hi_u24(b1s, h1 & 0xFFFFFF00u) + 2) >> 2;
             }
             packed |= max(v[0] & keep0, v[1] & keep1) << (8 * k);
         }
