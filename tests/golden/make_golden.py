@@ -125,7 +125,14 @@ def _install_standins():
     sys.modules["torchvision"] = tv
     sys.modules["torchvision.transforms"] = tvt
 
-    # cv2
+    # cv2: the reference is always executed over the stand-in below (the control-flow goldens keep their meaning on
+    # every machine); if the REAL library is importable (it is not in the build image) it is kept aside for make_cv2(),
+    # whose arithmetic goldens pin the oracle's restatement of INTER_LINEAR and BGR2GRAY
+    try:
+        import cv2 as _real_cv2  # type: ignore
+        _STATE["cv2_real"] = _real_cv2
+    except ImportError:
+        _STATE["cv2_real"] = None
     cv2 = types.ModuleType("cv2")
     cv2.INTER_LINEAR = 1
 
@@ -161,6 +168,10 @@ def _install_standins():
     cv2.VideoWriter_fourcc = lambda *c: "".join(c)
     sys.modules["cv2"] = cv2
 
+    _install_rest(gym)
+
+
+def _install_rest(gym):
     # dm_control.suite / dm_env.specs (dmc_env.py:15-16)
     import fake_dmc
     dmc = types.ModuleType("dm_control")
@@ -671,13 +682,34 @@ def make_dmc(dmc_env):
     ]
 
 
+# ------------------------------------------------------------------ third-party arithmetic (only where cv2 exists)
+def make_cv2():
+    """Inputs and cv2's own outputs for the two OpenCV operations the path uses; written only on a machine that has
+    cv2 (tests/test_oracle_resize.py::test_cv2_goldens_if_present checks the oracle against them when they exist)."""
+    cv2 = _STATE.get("cv2_real")
+    if cv2 is None:
+        return []
+    rng = np.random.default_rng(4242)
+    rec = {"cv2_version": cv2.__version__}
+    for i, ((h, w), (oh, ow)) in enumerate((((210, 160), (84, 84)), ((210, 160), (64, 64)), ((210, 160), (96, 96)))):
+        img = rng.integers(0, 256, (h, w), dtype=np.uint8)
+        rec[f"resize_in_{i}"] = img
+        rec[f"resize_out_{i}"] = cv2.resize(img, (ow, oh), interpolation=cv2.INTER_LINEAR)
+    rgb = rng.integers(0, 256, (84, 84, 3), dtype=np.uint8)
+    rec["gray_in"] = rgb
+    rec["gray_out"] = cv2.cvtColor(rgb, cv2.COLOR_BGR2GRAY)
+    path = os.path.join(HERE, "cv2_arithmetic.npz")
+    np.savez_compressed(path, **rec)
+    return [path]
+
+
 def main():
     if not os.path.isdir(REF):
         raise SystemExit(f"reference checkout not found at {REF}; goldens are generated in the build container only")
     _install_standins()
     fov_env, atari_env, dmc_env = _load_reference()
     gym = sys.modules["gymnasium"]
-    paths = make_fovea(fov_env, gym) + make_atari(atari_env) + make_record(fov_env, gym) + make_dmc(dmc_env) + make_spaces(fov_env, gym)
+    paths = make_fovea(fov_env, gym) + make_atari(atari_env) + make_record(fov_env, gym) + make_dmc(dmc_env) + make_spaces(fov_env, gym) + make_cv2()
     total = 0
     for p in paths:
         sz = os.path.getsize(p)
