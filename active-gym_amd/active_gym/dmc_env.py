@@ -104,7 +104,7 @@ class DMCHostRunner:
         self.current_state = [None] * self.num_envs
         self.internal_state = [None] * self.num_envs
         self.discount = np.empty(self.num_envs, dtype=object)
-        n_workers = workers if workers is not None else min(self.num_envs, os.cpu_count() or 1)
+        n_workers = workers if workers is not None else min(self.num_envs, os.cpu_count() or 1, 64)
         self._pool = ThreadPoolExecutor(max_workers=n_workers) if n_workers > 1 and self.num_envs > 1 else None
         self.training = True
 

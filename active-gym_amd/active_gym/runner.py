@@ -53,7 +53,7 @@ class AtariHostRunner:
             frames = np.zeros(shape, np.uint8)
         assert frames.shape == shape and frames.dtype == np.uint8
         self.frames = frames
-        n_workers = workers if workers is not None else min(self.num_envs, os.cpu_count() or 1)
+        n_workers = workers if workers is not None else min(self.num_envs, os.cpu_count() or 1, 64)
         self._pool = ThreadPoolExecutor(max_workers=n_workers) if n_workers > 1 else None
         self._n_workers = max(1, n_workers)
 

@@ -308,7 +308,9 @@ int agxr_create(const agxr_config *cfg, agxr_runner **out) {
     }
     r->lives.assign(cfg->num_envs, 0);
     r->life_termination.assign(cfg->num_envs, 0);
-    int nt = cfg->num_threads > 0 ? cfg->num_threads : (int)std::thread::hardware_concurrency();
+    // default: one worker per host core, but no more than 64 (measured on a 256-thread host: 64 workers step 1024 envs
+    // fastest; beyond that wake-up and cache traffic cost more than the extra cores give)
+    int nt = cfg->num_threads > 0 ? cfg->num_threads : std::min(64, (int)std::thread::hardware_concurrency());
     nt = std::max(1, std::min(nt, cfg->num_envs));
     r->pool = std::make_unique<Pool>(nt);
     *out = r.release();
