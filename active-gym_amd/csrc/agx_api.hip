@@ -15,6 +15,7 @@
 
 #include "agx.h"
 #include "agx_kernels.h"
+#include "agx_host_tables.h"
 
 using namespace agx;
 
@@ -38,6 +39,10 @@ struct agx_ctx {
     float *flex_w[6] = {};
     int4 *flex_meta[6] = {};
     size_t flex_tab_floats = 0;   // worst-case LDS floats of the staged tables
+    // K4 resize_to_full form (k_fovea_flexible3): composed per-axis operators, see agx_k4_flex3.h
+    Flex3Params f3{};
+    bool f3_ok = false;
+    std::vector<void *> owned;    // further device allocations freed by agx_destroy
     int band_rows = 0;
     int ingest_t = 256;
     int rows_touched = 0;
@@ -56,6 +61,7 @@ struct agx_ctx {
         int fused = 0;           // AGX_STEP_FUSED        agx_step_fixed as one heterogeneous launch + tail
         int generic = 0;         // AGX_FOVEA_GENERIC     K3 / K4 through the generic fallback kernel
         int no_full = 0;         // AGX_INGEST_NO_FULL    general k_ingest<256> even where k_ingest_full12 applies
+        int flex_v2 = 0;         // AGX_FLEX_V2           K4 resize_to_full through k_fovea_flexible2 (pass-by-pass form)
     } tune;
     std::string err;
 };
@@ -255,6 +261,17 @@ int upload(agx_ctx *ctx, T **dptr, const std::vector<T> &h) {
     return AGX_OK;
 }
 
+template <class T>
+int upload_owned(agx_ctx *ctx, const T **dptr, const std::vector<T> &h) {
+    T *d = nullptr;
+    const int rc = upload(ctx, &d, h);
+    if (rc == AGX_OK) {
+        ctx->owned.push_back(d);
+        *dptr = d;
+    }
+    return rc;
+}
+
 bool has_fovea(const agx_config &c) { return c.kind != AGX_KIND_BASE; }
 
 size_t fixed_lds(const agx_config &c) {
@@ -303,6 +320,8 @@ int agx_destroy(agx_ctx *ctx) {
                     ctx->flex_meta[0], ctx->flex_meta[1], ctx->flex_meta[2], ctx->flex_meta[3], ctx->flex_meta[4],
                     ctx->flex_meta[5]};
     for (void *p : ptrs)
+        if (p) (void)hipFree(p);
+    for (void *p : ctx->owned)
         if (p) (void)hipFree(p);
     delete ctx;
     return AGX_OK;
@@ -361,6 +380,7 @@ int agx_create(const agx_config *cfg, agx_ctx **out) {
     ctx->tune.fused = env_int("AGX_STEP_FUSED");
     ctx->tune.generic = env_int("AGX_FOVEA_GENERIC");
     ctx->tune.no_full = env_int("AGX_INGEST_NO_FULL");
+    ctx->tune.flex_v2 = env_int("AGX_FLEX_V2");
     DeviceGuard g(c.device);
     int rc = AGX_OK;
     auto bail = [&](int code) {
@@ -466,6 +486,23 @@ int agx_create(const agx_config *cfg, agx_ctx **out) {
             for (int r = 1; r <= c.obs_w; ++r) worst_w = std::max(worst_w, fam[0].floats[r] + fam[1].floats[r] + fam[2].floats[r]);
             for (int r = 1; r <= c.obs_h; ++r) worst_h = std::max(worst_h, fam[3].floats[r] + fam[4].floats[r] + fam[5].floats[r]);
             ctx->flex_tab_floats = worst_w + worst_h;
+            // resize_to_full: the composed-operator kernel where its plan applies (thread-per-column, <= 16 taps)
+            const Flex3Host f3 = build_flex3(c);
+            if (f3.ok && flex3_lds(f3, c) <= kMaxLds) {
+                Flex3Params &q = ctx->f3;
+                if ((rc = upload_owned(ctx, &q.wf, f3.wf)) != AGX_OK) return bail(rc);
+                if ((rc = upload_owned(ctx, &q.wc_meta, f3.wc_meta)) != AGX_OK) return bail(rc);
+                if ((rc = upload_owned(ctx, &q.wc_lo, f3.wc_lo)) != AGX_OK) return bail(rc);
+                if ((rc = upload_owned(ctx, &q.wc_w, f3.wc_w)) != AGX_OK) return bail(rc);
+                if ((rc = upload_owned(ctx, &q.hd_meta, f3.hd_meta)) != AGX_OK) return bail(rc);
+                if ((rc = upload_owned(ctx, &q.hd_lo, f3.hd_lo)) != AGX_OK) return bail(rc);
+                if ((rc = upload_owned(ctx, &q.hd_w, f3.hd_w)) != AGX_OK) return bail(rc);
+                if ((rc = upload_owned(ctx, &q.hy, f3.hy)) != AGX_OK) return bail(rc);
+                q.r0_bytes = f3.r0_bytes;
+                q.r1_bytes = f3.r1_bytes;
+                q.dp = f3.dp;
+                ctx->f3_ok = true;
+            }
         }
         if (c.kind == AGX_KIND_PERIPHERAL) {
             const int nin[4] = {c.obs_w, c.obs_h, c.per_w, c.per_h};
@@ -953,7 +990,15 @@ int agx_fovea_flexible(agx_ctx *ctx, const void *d_action, int action_dtype, con
     const GeomR gr{c.obs_h, c.obs_w, c.fov_h, c.fov_w};
     const bool generic_only = ctx->tune.generic != 0;                               // tuning / testing knob
     const size_t lds2 = flex2_lds(c, ctx->flex_tab_floats);
-    if (!generic_only && lds2 <= kMaxLds) {
+    if (!generic_only && ctx->f3_ok && ctx->tune.flex_v2 == 0) {
+        const size_t lds3 = (size_t)ctx->f3.r0_bytes + ctx->f3.r1_bytes + (size_t)c.obs_h * sizeof(int4);
+        const dim3 grid(c.frame_stack, c.num_envs), block(kThreads);
+        using GS = GeomS<84, 84, 30, 30>;
+        if (c.obs_h == 84 && c.obs_w == 84 && c.fov_h == 30 && c.fov_w == 30)
+            AGX_LAUNCH(1, (k_fovea_flexible3<GS>), grid, block, lds3, S(stream), GS{}, ctx->f3, p);
+        else
+            AGX_LAUNCH(1, (k_fovea_flexible3<GeomR>), grid, block, lds3, S(stream), gr, ctx->f3, p);
+    } else if (!generic_only && lds2 <= kMaxLds) {
         FlexParams g;
         TabFamily *fam[6] = {&g.wd, &g.wb, &g.wf, &g.hd, &g.hb, &g.hf};
         for (int k = 0; k < 6; ++k) {

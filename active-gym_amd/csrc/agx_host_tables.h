@@ -1,0 +1,110 @@
+// agx_host_tables.h - HOST side: the per-context operator tables of the composed-operator kernels
+// (k_fovea_flexible3, agx_k4_flex3.h), built from agx_rows.h.  Included by agx_api.hip and by the CPU test
+// harness tests/host_tables_harness.cpp, which replays the kernels' arithmetic from these very tables.
+#pragma once
+#include <cstring>
+#include <vector>
+
+#include "agx.h"
+#include "agx_common.h"
+#include "agx_k4_flex3.h"
+#include "agx_rows.h"
+
+namespace agx {
+
+// ---- K4 resize_to_full form: composed operators per window size (agx_k4_flex3.h, agx_rows.h)
+struct Flex3Host {
+    bool ok = false;
+    std::vector<Tap> wf;
+    std::vector<int2> wc_meta, hd_meta;
+    std::vector<int32_t> wc_lo, hd_lo;
+    std::vector<float> wc_w, hd_w;
+    std::vector<int4> hy;
+    int r0_bytes = 0, r1_bytes = 0, dp = 0;
+    size_t lds() const { return (size_t)r0_bytes + r1_bytes; }
+};
+
+inline int flex3_bucket(int n, int cap) { return n <= 4 ? 4 : (n <= 8 ? 8 : (n <= 16 && cap >= 16 ? 16 : 0)); }
+
+inline Flex3Host build_flex3(const agx_config &c) {
+    using namespace agx::rows;
+    Flex3Host h;
+    const int oh = c.obs_h, ow = c.obs_w, fh = c.fov_h, fw = c.fov_w;
+    const bool aa = c.antialias != 0;
+    // thread-per-column W passes, 8 lanes per squeezed row, byte-sized row indices
+    if (c.out_mode != AGX_OUT_RESIZE || ow > kThreads || fh > kThreads / 8 || oh > 1024) return h;
+    const int rstep = kThreads / ow;
+    const int erows = (fh + rstep - 1) / rstep * rstep;
+    h.dp = (ow + 7) & ~7;
+    h.r0_bytes = (int)((std::max((size_t)oh * ow + 8 * (size_t)ow + 32, (size_t)erows * ow * 4) + 15) & ~(size_t)15);
+    h.r1_bytes = (int)(((size_t)erows * h.dp * 4 + 15) & ~(size_t)15);
+    h.wf.assign((size_t)(ow + 1) * ow, Tap{0, 0, 0.f, 0.f});
+    h.wc_meta.assign(ow + 1, make_int2(4, 0));
+    h.wc_lo.assign((size_t)(ow + 1) * ow, 0);
+    h.hd_meta.assign(oh + 1, make_int2(4, 0));
+    h.hd_lo.assign((size_t)(oh + 1) * fh, 0);
+    h.hy.assign((size_t)(oh + 1) * oh, make_int4(0, 0, 0, 0));
+    for (int rw = 1; rw <= ow; ++rw) {
+        const Op fin = resize_axis(rw, ow, aa);
+        for (int x = 0; x < ow; ++x) {
+            Row r = fin[x];
+            trim(r);
+            if (r.w.size() > 2) return h;
+            const bool two = r.w.size() > 1;
+            h.wf[(size_t)rw * ow + x] = Tap{r.lo, two ? r.lo + 1 : r.lo, (float)(r.w[0] / 255.0), two ? (float)(r.w[1] / 255.0) : 0.f};
+        }
+        // squeeze path: crop -> Resize(fov) -> Resize(res) -> Resize(obs) along W
+        Op comp = compose(fin, compose(resize_axis(fw, rw, aa), resize_axis(rw, fw, aa)));
+        const int T = flex3_bucket(max_taps(comp), 16);
+        if (!T) return h;
+        fit(comp, rw, T);
+        h.wc_meta[rw] = make_int2(T, (int)h.wc_w.size());
+        for (int x = 0; x < ow; ++x) {
+            h.wc_lo[(size_t)rw * ow + x] = comp[x].lo;
+            for (int q = 0; q < T; ++q) h.wc_w.push_back(q < (int)comp[x].w.size() ? (float)comp[x].w[q] : 0.f);
+        }
+    }
+    for (int rh = 1; rh <= oh; ++rh) {
+        const bool squeeze = rh > fh;                                  // rows only, fov_env.py:286
+        const int er = squeeze ? fh : rh;                              // rows of E
+        Op fin = resize_axis(rh, oh, aa);
+        if (squeeze) {
+            Op d = resize_axis(rh, fh, aa);
+            const int T = flex3_bucket(max_taps(d), 8);
+            if (!T) return h;
+            fit(d, rh, T);
+            h.hd_meta[rh] = make_int2(T, (int)h.hd_w.size());
+            for (int y = 0; y < fh; ++y) {
+                h.hd_lo[(size_t)rh * fh + y] = d[y].lo;
+                for (int q = 0; q < T; ++q) h.hd_w.push_back(q < (int)d[y].w.size() ? (float)(d[y].w[q] / 255.0) : 0.f);
+            }
+            fin = compose(fin, resize_axis(fh, rh, aa));
+        }
+        for (int y = 0; y < oh; ++y) {
+            Row r = fin[y];
+            trim(r);
+            if (r.w.size() > 3 || er > 256) return h;
+            int idx[3];
+            float w[3];
+            for (int q = 0; q < 3; ++q) {
+                idx[q] = std::min(r.lo + q, er - 1);
+                w[q] = q < (int)r.w.size() ? (float)r.w[q] : 0.f;
+            }
+            int4 e;
+            e.x = idx[0] | (idx[1] << 8) | (idx[2] << 16);
+            memcpy(&e.y, &w[0], 4);
+            memcpy(&e.z, &w[1], 4);
+            memcpy(&e.w, &w[2], 4);
+            h.hy[(size_t)rh * oh + y] = e;
+        }
+    }
+    if (h.wc_w.empty()) h.wc_w.push_back(0.f);
+    if (h.hd_w.empty()) h.hd_w.assign(4, 0.f);
+    h.ok = true;
+    return h;
+}
+
+inline size_t flex3_lds(const Flex3Host &h, const agx_config &c) { return h.lds() + (size_t)c.obs_h * sizeof(int4); }
+
+
+}  // namespace agx

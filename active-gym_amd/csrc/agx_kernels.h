@@ -20,3 +20,4 @@
 #include "agx_fov_common.h"
 #include "agx_k2_fixed.h"
 #include "agx_k34_resample.h"
+#include "agx_k4_flex3.h"
