@@ -42,6 +42,10 @@ struct agx_ctx {
     // K4 resize_to_full form (k_fovea_flexible3): composed per-axis operators, see agx_k4_flex3.h
     Flex3Params f3{};
     bool f3_ok = false;
+    // K3 tuned form 3 (k_fovea_peripheral3)
+    Per3Params p3{};
+    int p3_mt = 0;
+    size_t p3_lds = 0;
     std::vector<void *> owned;    // further device allocations freed by agx_destroy
     int band_rows = 0;
     int ingest_t = 256;
@@ -62,6 +66,7 @@ struct agx_ctx {
         int generic = 0;         // AGX_FOVEA_GENERIC     K3 / K4 through the generic fallback kernel
         int no_full = 0;         // AGX_INGEST_NO_FULL    general k_ingest<256> even where k_ingest_full12 applies
         int flex_v2 = 0;         // AGX_FLEX_V2           K4 resize_to_full through k_fovea_flexible2 (pass-by-pass form)
+        int per_v2 = 0;          // AGX_PER_V2            K3 through k_fovea_peripheral2
     } tune;
     std::string err;
 };
@@ -381,6 +386,7 @@ int agx_create(const agx_config *cfg, agx_ctx **out) {
     ctx->tune.generic = env_int("AGX_FOVEA_GENERIC");
     ctx->tune.no_full = env_int("AGX_INGEST_NO_FULL");
     ctx->tune.flex_v2 = env_int("AGX_FLEX_V2");
+    ctx->tune.per_v2 = env_int("AGX_PER_V2");
     DeviceGuard g(c.device);
     int rc = AGX_OK;
     auto bail = [&](int code) {
@@ -515,6 +521,21 @@ int agx_create(const agx_config *cfg, agx_ctx **out) {
                     for (float &v : w) v = (float)((double)v / 255.0);
                 if ((rc = upload(ctx, &ctx->per_ln[k], ln)) != AGX_OK) return bail(rc);
                 if ((rc = upload(ctx, &ctx->per_w[k], w)) != AGX_OK) return bail(rc);
+            }
+        }
+        if (c.kind == AGX_KIND_PERIPHERAL) {
+            const Per3Host h3 = build_per3(c);
+            if (h3.ok && h3.lds <= kMaxLds) {
+                Per3Params &q = ctx->p3;
+                if ((rc = upload_owned(ctx, &q.lo0, h3.lo0)) != AGX_OK) return bail(rc);
+                if ((rc = upload_owned(ctx, &q.w0, h3.w0)) != AGX_OK) return bail(rc);
+                if ((rc = upload_owned(ctx, &q.lo1, h3.lo1)) != AGX_OK) return bail(rc);
+                if ((rc = upload_owned(ctx, &q.w1, h3.w1)) != AGX_OK) return bail(rc);
+                if ((rc = upload_owned(ctx, &q.x2, h3.x2)) != AGX_OK) return bail(rc);
+                if ((rc = upload_owned(ctx, &q.y3, h3.y3)) != AGX_OK) return bail(rc);
+                q.same = (c.per_h == c.obs_h && c.per_w == c.obs_w) ? 1 : 0;
+                ctx->p3_mt = h3.mt;
+                ctx->p3_lds = h3.lds;
             }
         }
         if (c.kind == AGX_KIND_FIXED && c.out_mode == AGX_OUT_RESIZE) {
@@ -946,6 +967,19 @@ int agx_fovea_peripheral(agx_ctx *ctx, const void *d_action, int action_dtype, c
     const FovParams p = fov_params(ctx, d_action, action_dtype, nullptr, d_mask, d_obs, d_fov_loc, nullptr);
     const GeomR gr{c.obs_h, c.obs_w, c.fov_h, c.fov_w};
     const bool generic_only = ctx->tune.generic != 0;                               // tuning / testing knob
+    if (!generic_only && ctx->p3_mt && ctx->tune.per_v2 == 0) {
+        const dim3 grid(c.frame_stack, c.num_envs), block(kThreads);
+        const size_t lds = ctx->p3_lds;
+        using GS = PGeomS<84, 84, 30, 30, 20, 20>;
+        const PGeomR pg{c.obs_h, c.obs_w, c.fov_h, c.fov_w, c.per_h, c.per_w};
+        const bool headline = c.obs_h == 84 && c.obs_w == 84 && c.fov_h == 30 && c.fov_w == 30 && c.per_h == 20 && c.per_w == 20;
+        if (headline && ctx->p3_mt == 12) AGX_LAUNCH(1, (k_fovea_peripheral3<GS, 12>), grid, block, lds, S(stream), GS{}, ctx->p3, p);
+        else if (headline && ctx->p3_mt == 4) AGX_LAUNCH(1, (k_fovea_peripheral3<GS, 4>), grid, block, lds, S(stream), GS{}, ctx->p3, p);
+        else if (ctx->p3_mt == 4) AGX_LAUNCH(1, (k_fovea_peripheral3<PGeomR, 4>), grid, block, lds, S(stream), pg, ctx->p3, p);
+        else if (ctx->p3_mt == 8) AGX_LAUNCH(1, (k_fovea_peripheral3<PGeomR, 8>), grid, block, lds, S(stream), pg, ctx->p3, p);
+        else if (ctx->p3_mt == 12) AGX_LAUNCH(1, (k_fovea_peripheral3<PGeomR, 12>), grid, block, lds, S(stream), pg, ctx->p3, p);
+        else AGX_LAUNCH(1, (k_fovea_peripheral3<PGeomR, 16>), grid, block, lds, S(stream), pg, ctx->p3, p);
+    } else
     // the tuned kernel keeps A | B | C with C 16-byte aligned and one row sweep per 256 threads
     if (!generic_only && per2_lds(c) <= kMaxLds && c.per_w <= kThreads) {
         PerParams g;

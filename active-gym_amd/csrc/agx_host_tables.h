@@ -7,6 +7,7 @@
 
 #include "agx.h"
 #include "agx_common.h"
+#include "agx_k3_per3.h"
 #include "agx_k4_flex3.h"
 #include "agx_rows.h"
 
@@ -106,5 +107,65 @@ inline Flex3Host build_flex3(const agx_config &c) {
 
 inline size_t flex3_lds(const Flex3Host &h, const agx_config &c) { return h.lds() + (size_t)c.obs_h * sizeof(int4); }
 
+
+// ---- K3 tuned form 3 (agx_k3_per3.h): the four passes' taps, the squeeze tables padded to one compile-time bound
+struct Per3Host {
+    bool ok = false;
+    int mt = 0;
+    std::vector<int32_t> lo0, lo1;
+    std::vector<float> w0, w1;
+    std::vector<Tap> x2;
+    std::vector<int4> y3;
+    size_t lds = 0;
+};
+
+inline Per3Host build_per3(const agx_config &c) {
+    using namespace agx::rows;
+    Per3Host h;
+    const int oh = c.obs_h, ow = c.obs_w, ph = c.per_h, pw = c.per_w;
+    const bool aa = c.antialias != 0;
+    if (ow > kThreads || pw > kThreads || ph > 256 || pw < 1 || ph < 1) return h;
+    Op s0 = resize_axis(ow, pw, aa), s1 = resize_axis(oh, ph, aa);
+    const Op e2 = resize_axis(pw, ow, aa), e3 = resize_axis(ph, oh, aa);
+    const int m = std::max(max_taps(s0), max_taps(s1));
+    h.mt = m <= 4 ? 4 : (m <= 8 ? 8 : (m <= 12 ? 12 : (m <= 16 ? 16 : 0)));
+    if (!h.mt || oh < h.mt || ow < h.mt || max_taps(e2) > 2 || max_taps(e3) > 2) return h;
+    fit(s0, ow, h.mt);
+    fit(s1, oh, h.mt);
+    for (int x = 0; x < pw; ++x) {
+        h.lo0.push_back(s0[x].lo);
+        for (int q = 0; q < h.mt; ++q) h.w0.push_back(q < (int)s0[x].w.size() ? (float)(s0[x].w[q] / 255.0) : 0.f);
+    }
+    for (int y = 0; y < ph; ++y) {
+        h.lo1.push_back(s1[y].lo);
+        for (int q = 0; q < h.mt; ++q) h.w1.push_back(q < (int)s1[y].w.size() ? (float)s1[y].w[q] : 0.f);
+    }
+    for (int x = 0; x < ow; ++x) {
+        Row r = e2[x];
+        trim(r);
+        const bool two = r.w.size() > 1;
+        h.x2.push_back(Tap{r.lo, two ? r.lo + 1 : r.lo, (float)r.w[0], two ? (float)r.w[1] : 0.f});
+    }
+    for (int y = 0; y < oh; ++y) {
+        Row r = e3[y];
+        trim(r);
+        const bool two = r.w.size() > 1;
+        const float w0 = (float)r.w[0], w1 = two ? (float)r.w[1] : 0.f;
+        int4 e;
+        e.x = r.lo | ((two ? r.lo + 1 : r.lo) << 8);
+        memcpy(&e.y, &w0, 4);
+        memcpy(&e.z, &w1, 4);
+        e.w = 0;
+        h.y3.push_back(e);
+    }
+    // LDS plan: must match the carve in k_fovea_peripheral3
+    const int per2 = kThreads / ow, crows = (ph + per2 - 1) / per2 * per2;
+    const size_t raw = ((size_t)oh * ow + 16 + 15) & ~(size_t)15;
+    const size_t ac = ((size_t)std::max(oh * pw, crows * ow) + 3) & ~(size_t)3;
+    const size_t b = ((size_t)crows * pw + 3) & ~(size_t)3;
+    h.lds = raw + (ac + b + (size_t)ph * h.mt + (((size_t)ph + 3) & ~(size_t)3)) * 4 + (size_t)oh * sizeof(int4);
+    h.ok = true;
+    return h;
+}
 
 }  // namespace agx

@@ -20,4 +20,5 @@
 #include "agx_fov_common.h"
 #include "agx_k2_fixed.h"
 #include "agx_k34_resample.h"
+#include "agx_k3_per3.h"
 #include "agx_k4_flex3.h"

@@ -4,7 +4,8 @@
 // (fov_env.py:276-298) evaluated pass by pass in double with the plain per-axis operators.  Also checks the memory
 // rules the kernel relies on (every LDS index inside the regions agx_create sizes).
 // Build: hipcc -std=c++17 -I include -I active-gym_amd/csrc tests/host_tables_harness.cpp -o <out>   (host code only)
-// Usage: harness oh ow fh fw antialias  -> prints "max_err <e> cases <n>" or "unsupported"
+// Usage: harness oh ow fh fw antialias          (k_fovea_flexible3 tables) -> "max_err <e> cases <n>" | "unsupported"
+//        harness per oh ow ph pw antialias      (k_fovea_peripheral3 tables + unit_fast over all 256 values)
 #include <cstdio>
 #include <cstdlib>
 #include <random>
@@ -41,7 +42,64 @@ static std::vector<double> resize(const std::vector<double> &x, int h, int w, in
     return apply_h(resize_axis(h, nh, aa), apply_w(resize_axis(w, nw, aa), x, h, w), nw, h);
 }
 
+static int per_main(int argc, char **argv) {
+    if (argc < 7) return 2;
+    for (int k = 0; k < 256; ++k)
+        if (unit_fast((float)k) != (float)k / 255.0f) { printf("unit_fast(%d) is not the IEEE quotient\n", k); return 1; }
+    agx_config c{};
+    c.obs_h = atoi(argv[2]); c.obs_w = atoi(argv[3]); c.per_h = atoi(argv[4]); c.per_w = atoi(argv[5]);
+    c.antialias = atoi(argv[6]);
+    const Per3Host h = build_per3(c);
+    if (!h.ok) { printf("unsupported\n"); return 0; }
+    const int oh = c.obs_h, ow = c.obs_w, ph = c.per_h, pw = c.per_w, MT = h.mt;
+    const bool aa = c.antialias != 0;
+    std::mt19937 rng(11);
+    std::vector<unsigned char> raw((size_t)oh * ow + 16, 0);
+    for (size_t i = 0; i < (size_t)oh * ow; ++i) raw[i] = (unsigned char)(rng() & 0xFF);
+    std::vector<float> A((size_t)oh * pw), B((size_t)ph * pw), C((size_t)ph * ow);
+    for (int y = 0; y < oh; ++y)
+        for (int x = 0; x < pw; ++x) {
+            const int off = y * ow + h.lo0[x];
+            if (((off & ~3) + 4 * ((MT + 6) / 4)) > oh * ow + 16) { printf("pass-0 read past the pad\n"); return 1; }
+            float acc = 0.f;
+            for (int q = 0; q < MT; ++q) acc = fmaf(h.w0[(size_t)x * MT + q], (float)raw[off + q], acc);
+            A[(size_t)y * pw + x] = acc;
+        }
+    for (int y = 0; y < ph; ++y)
+        for (int x = 0; x < pw; ++x) {
+            if (h.lo1[y] + MT > oh) { printf("pass-1 row past A\n"); return 1; }
+            float acc = 0.f;
+            for (int q = 0; q < MT; ++q) acc = fmaf(h.w1[(size_t)y * MT + q], A[(size_t)(h.lo1[y] + q) * pw + x], acc);
+            B[(size_t)y * pw + x] = acc;
+        }
+    for (int y = 0; y < ph; ++y)
+        for (int x = 0; x < ow; ++x) {
+            const Tap t = h.x2[x];
+            if (t.lo >= pw || t.aux >= pw) { printf("pass-2 column\n"); return 1; }
+            C[(size_t)y * ow + x] = fmaf(t.b, B[(size_t)y * pw + t.aux], t.a * B[(size_t)y * pw + t.lo]);
+        }
+    std::vector<double> x((size_t)oh * ow);
+    for (size_t i = 0; i < x.size(); ++i) x[i] = (double)raw[i] / 255.0;
+    const std::vector<double> ref = resize(resize(x, oh, ow, ph, pw, aa), ph, pw, oh, ow, aa);
+    double worst = 0;
+    for (int y = 0; y < oh; ++y) {
+        const int4 e = h.y3[y];
+        const int i0 = e.x & 0xFF, i1 = e.x >> 8;
+        if (i0 >= ph || i1 >= ph) { printf("pass-3 row\n"); return 1; }
+        float w0, w1;
+        memcpy(&w0, &e.y, 4); memcpy(&w1, &e.z, 4);
+        for (int xx = 0; xx < ow; ++xx) {
+            const float o = fmaf(w1, C[(size_t)i1 * ow + xx], w0 * C[(size_t)i0 * ow + xx]);
+            const double err = std::fabs((double)o - ref[(size_t)y * ow + xx]);
+            if (!(err <= worst)) worst = err;
+        }
+    }
+    printf("max_err %.3e mt %d lds %zu\n", worst, MT, h.lds);
+    return 0;
+}
+
 int main(int argc, char **argv) {
+    if (argc > 1 && !strcmp(argv[1], "per")) return per_main(argc, argv);
     if (argc < 6) return 2;
     agx_config c{};
     c.obs_h = atoi(argv[1]); c.obs_w = atoi(argv[2]); c.fov_h = atoi(argv[3]); c.fov_w = atoi(argv[4]);
