@@ -1,0 +1,94 @@
+"""BASELINE.json configs[2] and configs[3] at their full size (N = 1024 per GPU, 84x84 obs, 30x30 fovea, frame_stack 4):
+K3 (FixedFovealPeripheralEnv, peripheral_res 20x20) and K4 (FlexibleFovealEnv, per-env ragged windows) through the C
+ABI, checked against torch's own `interpolate` (the backend of torchvision's Resize, float64 like the reference feeds
+it: fov_env.py:276-298, 366-388) and against the NumPy clip / rint rules of the reference (fov_env.py:166-170,270-271,
+300-324).  Bars: indices and pasted / cropped pixels bit-exact, resized pixels within 1e-5."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+FLOAT_TOL = 1e-5
+N, FS, OBS, FOV = 1024, 4, 84, 30
+
+
+@pytest.fixture(scope="module")
+def dev():
+    return torch.device("cuda:0")
+
+
+def _pipe(**kw):
+    from active_gym import ObsPipeline
+    return ObsPipeline(num_envs=N, obs_size=(OBS, OBS), fov_size=(FOV, FOV), frame_stack=FS, fov_init_loc=(0, 0),
+                       sensory_action_mode="absolute", **kw)
+
+
+def _resize(x, size, aa):
+    """torchvision Resize(size)(x) on float64 [.., H, W]: unchanged when the size matches, else interpolate."""
+    if tuple(x.shape[-2:]) == tuple(size):
+        return x
+    return F.interpolate(x, size=size, mode="bilinear", align_corners=False, antialias=aa)
+
+
+@pytest.mark.parametrize("aa", [True, False])
+def test_peripheral_full_size(dev, aa):
+    g = torch.Generator(device="cpu").manual_seed(77 + aa)
+    p = _pipe(kind="peripheral", peripheral_res=(20, 20), antialias=aa)
+    for step in range(3):
+        st = torch.randint(0, 256, (N, FS, OBS, OBS), generator=g, dtype=torch.uint8).to(dev)
+        p.set_stack_u8(st)
+        a = torch.rand((N, 2), generator=g) * 65 - 5
+        if step == 1:
+            a[:8] = torch.tensor([[0.5, 1.5], [2.5, 53.5], [54.0, 54.0], [-3.0, 80.0], [12.5, 12.49], [53.51, 0.0], [27.0, 27.0], [1e9, -1e9]])
+        obs, loc = p.fovea(a.to(dev))
+        want_loc = np.rint(np.clip(a.numpy().astype(np.float64), 0, OBS - FOV)).astype(np.int32)       # fov_env.py:166-167
+        assert np.array_equal(loc.cpu().numpy(), want_loc)
+        full = p.observe_full()                                                                       # float32 k/255 (exact, tested elsewhere)
+        ref = _resize(_resize(full.double(), (20, 20), aa), (OBS, OBS), aa)                           # fov_env.py:375-377
+        ar = torch.arange(FOV, device=dev)
+        rows = (loc[:, 0:1] + ar).long()[:, None, :, None]
+        cols = (loc[:, 1:2] + ar).long()[:, None, None, :]
+        ni = torch.arange(N, device=dev)[:, None, None, None]
+        ci = torch.arange(FS, device=dev)[None, :, None, None]
+        assert torch.equal(obs[ni, ci, rows, cols], full[ni, ci, rows, cols]), "pasted fovea must be bit-exact"
+        ref[ni, ci, rows, cols] = full[ni, ci, rows, cols].double()                                   # fov_env.py:383-387
+        err = (obs.double() - ref).abs().max().item()
+        assert err <= FLOAT_TOL, (step, err)
+    p.close()
+
+
+@pytest.mark.parametrize("aa", [True, False])
+def test_flexible_full_size(dev, aa):
+    rng = np.random.default_rng(5 + aa)
+    p = _pipe(kind="flexible", resize_to_full=True, antialias=aa)
+    loc_w = np.zeros((N, 2), np.int64)                                    # the reference's state, NumPy rules
+    res_w = np.full((N, 2), FOV, np.int64)
+    worst = 0.0
+    for step in range(4):
+        st = torch.from_numpy(rng.integers(0, 256, (N, FS, OBS, OBS), dtype=np.uint8)).to(dev)
+        p.set_stack_u8(st)
+        types = rng.integers(0, 2, N).astype(np.int32)
+        a = np.where(types[:, None] == 1, rng.integers(10, 61, (N, 2)).astype(np.float64), rng.uniform(-5, 80, (N, 2)))
+        if step == 2:                                                    # edges of the resolution range
+            types[:6] = 1
+            a[:6] = [(84, 84), (31, 10), (1, 1), (30, 84), (84, 1), (60.5, 59.5)]
+        obs, loc, res = p.fovea(torch.from_numpy(a).to(dev), action_type=torch.from_numpy(types).to(dev))
+        # fov_env.py:300-324 (+ the ABI's documented rint / clamp of FOV_RES values)
+        is_res = types == 1
+        res_w = np.where(is_res[:, None], np.rint(np.clip(a, 1, OBS)).astype(np.int64), res_w)
+        loc_w = np.where(is_res[:, None], np.rint(np.clip(loc_w, 0, OBS - res_w)).astype(np.int64),
+                         np.rint(np.clip(a, 0, OBS - res_w)).astype(np.int64))
+        assert np.array_equal(res.cpu().numpy(), res_w) and np.array_equal(loc.cpu().numpy(), loc_w), step
+        full = p.observe_full().double()
+        errs = []
+        for i in range(N):
+            (r, c), (rh, rw) = loc_w[i], res_w[i]
+            x = full[i:i + 1, :, r:r + rh, c:c + rw]
+            if rh > FOV:                                                  # rows only, fov_env.py:286
+                x = _resize(_resize(x, (FOV, FOV), aa), (int(rh), int(rw)), aa)
+            x = _resize(x, (OBS, OBS), aa)
+            errs.append((obs[i:i + 1].double() - x).abs().max())
+        worst = max(worst, torch.stack(errs).max().item())
+        assert worst <= FLOAT_TOL, (step, worst)
+    p.close()

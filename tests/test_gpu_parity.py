@@ -585,7 +585,7 @@ def test_ingest_gray_raw_matches_oracle_and_rgb_path(dev, obs):
 
 # ---------------------------------------------------------------- every tuning variant == the default, bit for bit
 _KNOBS = ("AGX_INGEST_NO_FULL", "AGX_INGEST_T", "AGX_INGEST_BAND_ROWS", "AGX_INGEST_PIPE", "AGX_INGEST_WAVE", "AGX_FOVEA_PAIR", "AGX_STEP_FUSED",
-          "AGX_FOVEA_GENERIC")
+          "AGX_FOVEA_GENERIC", "AGX_PER_V2", "AGX_FLEX_V2")
 
 
 @pytest.mark.parametrize("knob", [{"AGX_INGEST_T": "128"}, {"AGX_INGEST_BAND_ROWS": "7"}, {"AGX_INGEST_BAND_ROWS": "11"},
@@ -629,18 +629,24 @@ def test_kernel_variants_bit_identical(dev, knob, monkeypatch):
     v_.close()
 
 
+@pytest.mark.parametrize("knob", ["AGX_FOVEA_GENERIC", "V2"])
 @pytest.mark.parametrize("kind", ["peripheral", "flexible"])
-def test_generic_fallback_kernel_matches_tuned(dev, kind, monkeypatch):
+def test_generic_fallback_kernel_matches_tuned(dev, kind, knob, monkeypatch):
     """AGX_FOVEA_GENERIC routes K3 / K4 through k_fovea_generic (the fallback for geometries whose tables do not fit
-    the tuned kernels' LDS plan); same results up to float summation order."""
+    the tuned kernels' LDS plan), AGX_PER_V2 / AGX_FLEX_V2 through the pass-by-pass tuned forms (k_fovea_peripheral2 /
+    k_fovea_flexible2: the fallbacks for tap counts outside the composed-operator kernels' plan); same results up to
+    float summation order."""
+    if knob == "V2":
+        knob = "AGX_PER_V2" if kind == "peripheral" else "AGX_FLEX_V2"
     N, fs = 19, 4
     kw = dict(num_envs=N, kind=kind, obs_size=(84, 84), fov_size=(30, 30), frame_stack=fs, resize_to_full=True,
               fov_init_loc=(0, 0), sensory_action_mode="absolute")
     if kind == "peripheral":
         kw["peripheral_res"] = (20, 20)
-    monkeypatch.delenv("AGX_FOVEA_GENERIC", raising=False)
+    for k_ in ("AGX_FOVEA_GENERIC", "AGX_PER_V2", "AGX_FLEX_V2"):
+        monkeypatch.delenv(k_, raising=False)
     d = _pipe(**kw)
-    monkeypatch.setenv("AGX_FOVEA_GENERIC", "1")
+    monkeypatch.setenv(knob, "1")
     g = _pipe(**kw)
     rng = np.random.default_rng(12)
     for step in range(6):
