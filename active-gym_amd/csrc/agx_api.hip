@@ -47,6 +47,9 @@ struct agx_ctx {
     int p3_mt = 0;
     size_t p3_lds = 0;
     std::vector<void *> owned;    // further device allocations freed by agx_destroy
+    // split step (agx_step_fixed): env-range parts 1.. run on these internal streams, forked from / joined to the caller's
+    hipStream_t aux[3] = {nullptr, nullptr, nullptr};
+    hipEvent_t ev_fork = nullptr, ev_join[3] = {nullptr, nullptr, nullptr};
     int band_rows = 0;
     int ingest_t = 256;
     int rows_touched = 0;
@@ -67,6 +70,8 @@ struct agx_ctx {
         int no_full = 0;         // AGX_INGEST_NO_FULL    general k_ingest<256> even where k_ingest_full12 applies
         int flex_v2 = 0;         // AGX_FLEX_V2           K4 resize_to_full through k_fovea_flexible2 (pass-by-pass form)
         int per_v2 = 0;          // AGX_PER_V2            K3 through k_fovea_peripheral2
+        int split = 0;           // AGX_STEP_SPLIT        env-range parts of agx_step_fixed on internal streams (default 1 = one launch pair)
+        int aux_prio = 0;        // AGX_STEP_AUX_PRIO     -1 | 0 | 1: priority of the internal streams relative to normal
     } tune;
     std::string err;
 };
@@ -328,6 +333,11 @@ int agx_destroy(agx_ctx *ctx) {
         if (p) (void)hipFree(p);
     for (void *p : ctx->owned)
         if (p) (void)hipFree(p);
+    for (hipStream_t st : ctx->aux)
+        if (st) (void)hipStreamDestroy(st);
+    if (ctx->ev_fork) (void)hipEventDestroy(ctx->ev_fork);
+    for (hipEvent_t e : ctx->ev_join)
+        if (e) (void)hipEventDestroy(e);
     delete ctx;
     return AGX_OK;
 }
@@ -387,6 +397,8 @@ int agx_create(const agx_config *cfg, agx_ctx **out) {
     ctx->tune.no_full = env_int("AGX_INGEST_NO_FULL");
     ctx->tune.flex_v2 = env_int("AGX_FLEX_V2");
     ctx->tune.per_v2 = env_int("AGX_PER_V2");
+    ctx->tune.split = env_int("AGX_STEP_SPLIT");
+    ctx->tune.aux_prio = env_int("AGX_STEP_AUX_PRIO", 0);
     DeviceGuard g(c.device);
     int rc = AGX_OK;
     auto bail = [&](int code) {
@@ -920,6 +932,92 @@ int agx_step_fixed(agx_ctx *ctx, const uint8_t *d_frames, const uint8_t *d_cmd, 
     // bit-identical and measured a tie at N=1024 (69.3 vs 67.9 us per step: it fills the ingest's drain but its
     // second launch is one latency chain long), so the default is the two stand-alone launches.
     const bool fused = ctx->tune.fused != 0;                                    // tuning / testing knob
+    // ---- split step: the batch as P env ranges, range 0 on the caller's stream, the others on internal streams forked
+    // from it and joined back before the call returns its work to the caller's stream order.  One range's fovea stores
+    // and ingest drain then run under another range's ingest loads (reads and writes of the same step overlap), with
+    // the results of one launch pair bit for bit (same kernels, disjoint env ranges, no shared state).
+    const agx_ctx::Tune &tn = ctx->tune;
+    const bool default_forms = !fused && !tn.ingest_t && !tn.band_rows && !tn.pipe_parts && !tn.wave && !tn.pair && !tn.no_full;
+    // Measured at N=1024 (same box, bench.py --steps 600): one launch pair 60.9 us per step; 2 parts 72.7 (69.3 with
+    // low-priority internal streams, 75.1 with high), 3 parts 86.6, 4 parts 105: every cross-stream event edge costs more
+    // than the overlap returns (round 1's +6-10 % came from two independent contexts that never join).  So it is opt-in.
+    int parts = tn.split > 0 ? tn.split : 1;
+    parts = std::min(std::min(parts, 4), c.num_envs);
+    if (parts > 1 && default_forms && c.obs_h == c.obs_w && !mid_event) {
+        DeviceGuard g(c.device);
+        if (!ctx->ev_fork) {
+            int lo_p = 0, hi_p = 0;
+            AGX_HIP(ctx, hipDeviceGetStreamPriorityRange(&lo_p, &hi_p));        // lo_p: least urgent (largest number)
+            const int prio = tn.aux_prio > 0 ? hi_p : (tn.aux_prio < 0 ? lo_p : 0);
+            for (int k = 0; k < 3; ++k) {
+                AGX_HIP(ctx, hipStreamCreateWithPriority(&ctx->aux[k], hipStreamNonBlocking, prio));
+                AGX_HIP(ctx, hipEventCreateWithFlags(&ctx->ev_join[k], hipEventDisableTiming));
+            }
+            AGX_HIP(ctx, hipEventCreateWithFlags(&ctx->ev_fork, hipEventDisableTiming));
+        }
+        hipStream_t st[4] = {S(stream), ctx->aux[0], ctx->aux[1], ctx->aux[2]};
+        AGX_HIP(ctx, hipEventRecord(ctx->ev_fork, st[0]));
+        for (int k = 1; k < parts; ++k) AGX_HIP(ctx, hipStreamWaitEvent(st[k], ctx->ev_fork, 0));
+        const size_t fsz = (size_t)c.obs_h * c.obs_w;
+        const bool crop = c.out_mode == AGX_OUT_RAW;
+        const size_t obs_env = (size_t)c.frame_stack * (crop ? (size_t)c.fov_h * c.fov_w : fsz);
+        const bool wide = action_dtype == AGX_DT_F64 || action_dtype == AGX_DT_I64;
+        const bool full12 = ctx->y_affine && ctx->band_rows == 12 && c.obs_h % 12 == 0;
+        const bool headline = c.obs_h == 84 && c.obs_w == 84 && c.fov_h == 30 && c.fov_w == 30;
+        using GS = GeomS<84, 84, 30, 30>;
+        const GeomR gr{c.obs_h, c.obs_w, c.fov_h, c.fov_w};
+        int n0[5];
+        for (int k = 0; k <= parts; ++k) n0[k] = (int)((long long)c.num_envs * k / parts);
+        const IngestParams pi0 = ingest_params(ctx, d_frames, d_cmd);
+        for (int k = 0; k < parts; ++k) {
+            IngestParams q = pi0;
+            const size_t b = n0[k];
+            q.frames += b * 2 * (size_t)kRawFrameBytes;
+            q.cmd += b;
+            q.ring += b * c.frame_stack * fsz;
+            q.head_in += b;
+            q.head_out += b;
+            const dim3 grid(q.nbands, n0[k + 1] - n0[k]);
+            if (full12) hipLaunchKernelGGL(k_ingest_full12_part, grid, dim3(kThreads), ingest_lds(ctx), st[k], q);
+            else hipLaunchKernelGGL(k_ingest_part, grid, dim3(kThreads), ingest_lds(ctx), st[k], q);
+        }
+        AGX_HIP(ctx, hipGetLastError());
+        ctx->cur_head ^= 1;
+        const FovParams pf0 = fov_params(ctx, d_action, action_dtype, nullptr, nullptr, d_obs, d_fov_loc, nullptr);
+        for (int k = 0; k < parts; ++k) {
+            FovParams q = pf0;
+            const size_t b = n0[k];
+            q.ring += b * c.frame_stack * fsz;
+            q.head += b;
+            q.loc_in += 2 * b;
+            q.loc_out += 2 * b;
+            q.res_in += 2 * b;
+            q.res_out += 2 * b;
+            if (q.action) q.action = static_cast<const char *>(q.action) + b * (wide ? 16 : 8);
+            q.obs += b * obs_env;
+            if (q.user_loc) q.user_loc += 2 * b;
+            const dim3 grid(c.frame_stack, n0[k + 1] - n0[k]);
+            const size_t lds = fixed_lds(c);
+#define LAUNCH_PART(MODE)                                                                                              \
+    do {                                                                                                               \
+        if (headline) hipLaunchKernelGGL((k_fovea_fixed_part<GS, MODE>), grid, dim3(kThreads), lds, st[k], GS{}, q);   \
+        else hipLaunchKernelGGL((k_fovea_fixed_part<GeomR, MODE>), grid, dim3(kThreads), lds, st[k], gr, q);           \
+    } while (0)
+            switch (c.out_mode) {
+                case AGX_OUT_RAW: LAUNCH_PART(AGX_OUT_RAW); break;
+                case AGX_OUT_MASK: LAUNCH_PART(AGX_OUT_MASK); break;
+                default: LAUNCH_PART(AGX_OUT_RESIZE); break;
+            }
+#undef LAUNCH_PART
+        }
+        AGX_HIP(ctx, hipGetLastError());
+        ctx->cur_fov ^= 1;
+        for (int k = 1; k < parts; ++k) {
+            AGX_HIP(ctx, hipEventRecord(ctx->ev_join[k - 1], st[k]));
+            AGX_HIP(ctx, hipStreamWaitEvent(st[0], ctx->ev_join[k - 1], 0));
+        }
+        return AGX_OK;
+    }
     if (c.out_mode != AGX_OUT_RESIZE || ctx->ingest_t != 256 || !fused || c.obs_h != c.obs_w) {
         // the two stand-alone launches, same results
         rc = agx_ingest(ctx, d_frames, d_cmd, stream);

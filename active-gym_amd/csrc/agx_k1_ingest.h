@@ -321,6 +321,17 @@ __global__ __launch_bounds__(kThreads) void k_ingest_full12(IngestParams p) {
     ingest_band<kThreads, false, 12>(p, blockIdx.x, blockIdx.y, smem);
 }
 
+// The same two kernels under names of their own, for the env-range parts of a split step (agx_step_fixed): a kernel
+// trace then tells the concurrently running part launches from the stand-alone full-batch launches.
+__global__ __launch_bounds__(kThreads) void k_ingest_part(IngestParams p) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    ingest_band<kThreads>(p, blockIdx.x, blockIdx.y, smem);
+}
+__global__ __launch_bounds__(kThreads) void k_ingest_full12_part(IngestParams p) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    ingest_band<kThreads, false, 12>(p, blockIdx.x, blockIdx.y, smem);
+}
+
 // K1g: the same from ALE grayscale screens u8 [N][2][210][160] (agx_ingest_gray_raw)
 __global__ __launch_bounds__(kThreads) void k_ingest_grayraw(IngestParams p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];

@@ -181,6 +181,13 @@ __global__ __launch_bounds__(kThreads) void k_fovea_fixed(G g, FovParams p) {
     fovea_fixed_body<G, MODE>(g, p, blockIdx.x, blockIdx.y, smem);
 }
 
+// env-range part of a split step (agx_step_fixed): same body, a name of its own in kernel traces
+template <class G, int MODE>
+__global__ __launch_bounds__(kThreads) void k_fovea_fixed_part(G g, FovParams p) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    fovea_fixed_body<G, MODE>(g, p, blockIdx.x, blockIdx.y, smem);
+}
+
 // ---------------------------------------------------------------------------------------------
 // K2, two slots per workgroup (resize_to_full, stand-alone launch): grid = (fs/2, N), block = 256.
 // The occupancy timeline of the one-slot form shows two synchronized rounds of workgroups, each wave

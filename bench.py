@@ -45,6 +45,9 @@ def parse():
     ap.add_argument("--no-events", action="store_true", help="skip per-kernel HIP events in the timed region")
     ap.add_argument("--fused", action="store_true",
                     help="fixed kind: use agx_step_fixed's heterogeneous launch (sets AGX_STEP_FUSED=1; measured a tie)")
+    ap.add_argument("--split", action="store_true",
+                    help="fixed kind: agx_step_fixed's split step (AGX_STEP_SPLIT env-range parts on internal streams: one "
+                         "part's stores under another part's loads; measured slower than the two stand-alone launches)")
     ap.add_argument("--event-mode", default="kernel", choices=("kernel", "stream"),
                     help="kernel: start/stop HIP events stamped by the launch itself (hipExtLaunchKernelGGL through "
                          "agx_profile_next: the kernel's own begin/end, what rocprofv3 reports); stream: events recorded "
@@ -248,6 +251,9 @@ def main():
     res_out = torch.empty((n, 2), dtype=torch.int32, device=dev)
 
     fused = args.kind == "fixed" and args.fused and os.environ.get("AGX_STEP_FUSED") is not None
+    # --split: agx_step_fixed's split step; the sampled steps (every M-th) still run as two stand-alone full-batch
+    # launches carrying their own HIP events - the per-kernel roofline is a solo figure
+    split = args.kind == "fixed" and not gray and not fused and args.split
 
     kernel_events = args.event_mode == "kernel" and not fused
 
@@ -255,13 +261,16 @@ def main():
         """One pass of the hot path over batch k of the pool; `e` = the HIP events of a sampled step: 4 stamped by
         its two launches themselves (kernel mode) or 3 recorded on the stream around them (stream mode)."""
         i = k % args.pool
+        sampled = e is not None
         if e is not None and kernel_events:
             pipe.profile_next("ingest", e[0], e[1])
             pipe.profile_next("fovea", e[2], e[3])
             e = None
         if e is not None:
             e[0].record()
-        if fused:
+        if split and not sampled:
+            pipe.step_fixed(frames[i], cmds[i], acts[i], out=obs, loc_out=loc)
+        elif fused:
             # launch 1: ingest bands + fovea of the untouched ring slots; launch 2: fovea of the written slot
             pipe.step_fixed(frames[i], cmds[i], acts[i], out=obs, loc_out=loc, mid_event=None if e is None else e[1])
         else:
@@ -337,6 +346,9 @@ def main():
                                    + ("device-resident synthetic RGB frames (BASELINE.json configs[1])" if not gray else
                                       "device-resident synthetic GRAY screens (getScreenGrayscale format) - NOT the metric's workload"),
                        "envs_per_gpu": n, "total_envs": total_envs, "input_pool": args.pool,
+                       "step_form": ("agx_step_fixed split step (env-range parts on internal streams, AGX_STEP_SPLIT=%s); every %dth "
+                                     "step as two stand-alone full-batch launches carrying the roofline's HIP events"
+                                     % (os.environ.get("AGX_STEP_SPLIT", "default 2"), M)) if split else "two stand-alone launches per step",
                        "parallelism": f"env-shard x{world}, no collective"},
             "roofline": roof, "kernels": kernels,
         }
