@@ -37,6 +37,7 @@ class AgxConfig(C.Structure):
 _P = C.c_void_p
 SIGNATURES = {
     "agx_abi_version": (C.c_int, []),
+    "agx_build_info": (C.c_char_p, []),
     "agx_create": (C.c_int, [C.POINTER(AgxConfig), C.POINTER(_P)]),
     "agx_destroy": (C.c_int, [_P]),
     "agx_last_error": (C.c_char_p, [_P]),
@@ -88,6 +89,11 @@ def lib():
         raise ImportError(f"{path}: ABI version {v}, binding expects {ABI_VERSION}")
     _lib = handle
     return _lib
+
+
+def build_info() -> str:
+    """"libagx abi <v> src <hash>": which sources the loaded library was built from."""
+    return lib().agx_build_info().decode()
 
 
 def last_error(ctx=None):

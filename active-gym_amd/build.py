@@ -27,6 +27,16 @@ def hipcc():
     raise RuntimeError("hipcc not found (set HIPCC=...)")
 
 
+def source_hash():
+    """SHA-256 prefix over the sources libagx.so is compiled from (what agx_build_info() reports)."""
+    import hashlib
+    h = hashlib.sha256()
+    for d in DEPS:
+        h.update(os.path.basename(d).encode() + b"\0")
+        h.update(open(d, "rb").read())
+    return h.hexdigest()[:12]
+
+
 def up_to_date():
     return os.path.exists(OUT) and all(os.path.getmtime(OUT) >= os.path.getmtime(d) for d in DEPS)
 
@@ -38,7 +48,7 @@ def build(force=False, verbose=False, extra=()):
     cmd = [hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared",
            "-fvisibility=hidden", "-Wall", "-Wno-unused-function",
            "-I", os.path.join(REPO, "include"), "-I", os.path.join(HERE, "csrc"),
-           "-DAGX_BUILD", *extra, SRC, "-o", OUT + ".tmp"]
+           "-DAGX_BUILD", f'-DAGX_SRC_HASH="{source_hash()}"', *extra, SRC, "-o", OUT + ".tmp"]
     if verbose:
         print(" ".join(cmd))
     subprocess.run(cmd, check=True)

@@ -316,6 +316,13 @@ extern "C" {
 
 int agx_abi_version(void) { return AGX_ABI_VERSION; }
 
+#ifndef AGX_SRC_HASH
+#define AGX_SRC_HASH "unknown"
+#endif
+#define AGX_STR2(x) #x
+#define AGX_STR(x) AGX_STR2(x)
+const char *agx_build_info(void) { return "libagx abi " AGX_STR(AGX_ABI_VERSION) " src " AGX_SRC_HASH; }
+
 const char *agx_last_error(const agx_ctx *ctx) { return ctx ? ctx->err.c_str() : g_create_err.c_str(); }
 
 int agx_destroy(agx_ctx *ctx) {

@@ -39,6 +39,7 @@ def parse():
     ap.add_argument("--pool", type=int, default=8, help="distinct synthetic input batches cycled through")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="budget of the CPU-baseline sample")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-e2e", action="store_true", help="skip the PCIe-inclusive AtariVecEnv leg (the `e2e` key)")
     ap.add_argument("--frame-format", default="rgb", choices=("rgb", "gray"),
                     help="rgb = the metric's workload (raw RGB screens, luminance on the device); gray = ALE grayscale "
                          "screens in (agx_ingest_gray_raw) - a different, lighter workload, reported for DESIGN.md only")
@@ -106,75 +107,208 @@ print(json.dumps({"steps": n * reps, "wall": time.perf_counter() - t0}))
 """
 
 
+def _build_info():
+    from active_gym import _native as nat
+    return nat.build_info()
+
+
+def host_cores():
+    """Host cores of this box: present, and usable by this job (scheduler affinity and the cgroup CPU quota)."""
+    present = os.cpu_count() or 1
+    try:
+        aff = len(os.sched_getaffinity(0))
+    except AttributeError:
+        aff = present
+    quota = None
+    for path in ("/sys/fs/cgroup/cpu.max", "/sys/fs/cgroup/cpu/cpu.cfs_quota_us"):
+        try:
+            txt = open(path).read().split()
+            if path.endswith("cpu.max"):
+                if txt[0] != "max":
+                    quota = float(txt[0]) / float(txt[1])
+            else:
+                q = float(txt[0])
+                if q > 0:
+                    quota = q / float(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            break
+        except (OSError, ValueError, IndexError):
+            continue
+    usable = aff if quota is None else max(1, min(aff, int(quota + 0.5)))
+    return {"present": present, "affinity": aff, "cgroup_quota": quota, "usable": usable}
+
+
+def cpu_reference_shaped(budget_s, seed):
+    """The reference's own shape of the work: one env after the other like
+    SyncVectorEnv (atari_env.py:241), each step in NumPy float64 + torch's CPU `interpolate` on one thread:
+    gray + cv2-style resize of the two sampled screens (oracle restatement, atari_env.py:73-75), max, deque append,
+    np.stack (atari_env.py:121-143), clip/rint, crop, Resize(obs_size) (fov_env.py:166-183)."""
+    import collections
+    import numpy as np
+    import torch
+    import torch.nn.functional as F
+    from oracle import oracle as O
+    n = 8
+    rng = np.random.default_rng(seed)
+    frames = rng.integers(0, 256, (n, 2, 210, 160, 3), dtype=np.uint8)
+    acts = rng.uniform(-5, 60, (n, 2))
+    dq = [collections.deque([np.zeros((84, 84)) for _ in range(4)], maxlen=4) for _ in range(n)]
+    nthr = torch.get_num_threads()
+    torch.set_num_threads(1)
+    try:
+        t0 = time.perf_counter()
+        reps = 0
+        while time.perf_counter() - t0 < budget_s:
+            for i in range(n):
+                fb = np.zeros((2, 84, 84))
+                for f in range(2):
+                    fb[f] = O.get_state_u8(frames[i, f], (84, 84)).astype(np.float32) / 255.
+                dq[i].append(fb.max(0))
+                state = np.stack(dq[i], 0)
+                loc = np.rint(np.clip(acts[i], 0, 54)).astype(int)
+                fov = state[..., loc[0]:loc[0] + 30, loc[1]:loc[1] + 30]
+                F.interpolate(torch.from_numpy(fov)[None], size=(84, 84), mode="bilinear", align_corners=False, antialias=True)[0].numpy()
+            reps += 1
+        el = time.perf_counter() - t0
+    finally:
+        torch.set_num_threads(nthr)
+    return {"value": n * reps / el, "unit": "env steps/s", "cores": 1, "kind": "port",
+            "sample": f"{n} envs x {reps} steps of the same config, one env after the other (SyncVectorEnv shape), NumPy float64 + "
+                      f"oracle gray/cv-resize restatement + torch CPU interpolate on 1 thread, {el:.1f} s"}
+
+
 def cpu_baseline(budget_s, seed):
     """The oracle (a per-env CPU port of the reference's NumPy/OpenCV/torchvision arithmetic: oracle/cport.c,
-    falling back to oracle/oracle.py) timed on this box's host cores over a bounded sample of the same workload.
-    With the C port every core steps its own 16 envs serially (one SyncVectorEnv per core); the children are
-    plain subprocesses that import neither torch nor HIP, each under a hard timeout."""
+    falling back to oracle/oracle.py) timed on this box's host cores over a bounded sample of the same workload:
+    one process per core usable by this job, each stepping its own 16 envs serially (one SyncVectorEnv per core); the
+    children are plain subprocesses that import neither torch nor HIP, each under a hard timeout.  Beside it,
+    `reference_shaped`: the reference's own serial NumPy/torch shape of the work on one core."""
     import numpy as np
+    hc = host_cores()
     try:
         from oracle import cport
         have_c = cport.available()
     except Exception:
         have_c = False
     n = 16
+    out = None
     if have_c:
-        cores = max(1, min(os.cpu_count() or 1, 16))
+        cores = max(1, min(hc["usable"], 512))
         cmd = lambda i: [sys.executable, "-c", _CPU_CHILD, REPO, str(seed + i), str(n), str(budget_s)]
         procs = [subprocess.Popen(cmd(i), stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, text=True) for i in range(cores)]
         res = []
         for pr in procs:
             try:
-                out, _ = pr.communicate(timeout=budget_s + 60)
-                res.append(json.loads(out.strip().splitlines()[-1]))
+                o, _ = pr.communicate(timeout=budget_s + 90)
+                res.append(json.loads(o.strip().splitlines()[-1]))
             except Exception:  # noqa: BLE001 - a stuck or failed child is dropped, never waited for
                 pr.kill()
         if res:
             steps = sum(r["steps"] for r in res)
             wall = max(r["wall"] for r in res)
-            return {"value": steps / wall, "unit": "env steps/s", "cores": len(res), "kind": "port",
-                    "sample": f"{len(res)} processes x {n} envs of the same config, each stepped serially through "
-                              f"oracle/cport.c (C, -O2) for {wall:.1f} s ({steps / wall / len(res):.0f} env steps/s per core)"}
-    from oracle import oracle as O
-    rng = np.random.default_rng(seed)
-    frames = rng.integers(0, 256, (n, 2, 210, 160, 3), dtype=np.uint8)
-    acts = rng.uniform(-5, 60, (n, 2))
-    kw = dict(obs_size=(84, 84), fov_size=(30, 30), fov_init_loc=(0, 0), sensory_action_mode="absolute",
-              resize_to_full=True)
-    ring = O.RingOracle(n, 4, (84, 84))
-    fov = [O.FixedFovealOracle(**kw) for _ in range(n)]
+            out = {"value": steps / wall, "unit": "env steps/s", "cores": len(res), "kind": "port",
+                   "cores_present": hc["present"], "cores_usable": hc["usable"], "per_core": steps / wall / len(res),
+                   "sample": f"{len(res)} processes (every core this job may use: {hc['usable']} of {hc['present']} present; "
+                             f"affinity {hc['affinity']}, cgroup quota {hc['cgroup_quota']}) x {n} envs of the same config, each stepped "
+                             f"serially through oracle/cport.c (C, -O2) for {wall:.1f} s"}
+    if out is None:
+        from oracle import oracle as O
+        rng = np.random.default_rng(seed)
+        frames = rng.integers(0, 256, (n, 2, 210, 160, 3), dtype=np.uint8)
+        acts = rng.uniform(-5, 60, (n, 2))
+        kw = dict(obs_size=(84, 84), fov_size=(30, 30), fov_init_loc=(0, 0), sensory_action_mode="absolute",
+                  resize_to_full=True)
+        ring = O.RingOracle(n, 4, (84, 84))
+        fov = [O.FixedFovealOracle(**kw) for _ in range(n)]
+        t0 = time.perf_counter()
+        reps = 0
+        while time.perf_counter() - t0 < budget_s:
+            ring.ingest(frames, np.full(n, 2))
+            full = ring.full_state()
+            for i in range(n):
+                fov[i].step(full[i], acts[i])
+            reps += 1
+        el = time.perf_counter() - t0
+        out = {"value": n * reps / el, "unit": "env steps/s", "cores": 1, "kind": "port", "cores_present": hc["present"],
+               "cores_usable": hc["usable"],
+               "sample": f"{n} envs x {reps} steps of the same config through oracle/oracle.py (NumPy, single thread), {el:.1f} s"}
+    try:
+        out["reference_shaped"] = cpu_reference_shaped(min(6.0, budget_s), seed)
+    except Exception as e:  # noqa: BLE001
+        out["reference_shaped"] = {"error": repr(e)}
+    return out
+
+
+def run_e2e(dev, n, hc):
+    """PCIe- and emulator-inclusive rate through the drop-in API (never `value`): AtariVecEnv.step = native C++ host
+    runner (scripted emulator, one thread per core) -> pinned staging -> chunked hipMemcpyAsync -> ingest + fovea ->
+    device observations; RGB screens (the metric's input format, north_star) and ALE grayscale screens (what the
+    reference reads, atari_env.py:74).  Bounded: a few dozen steps each."""
+    import numpy as np
+    import torch
+    from active_gym import AtariEnvArgs, AtariVecEnv
+    workers = max(1, min(64, hc["usable"]))
+    out = {"envs": n, "runner": "libagx_runner.so (C++ threads, scripted emulator)", "workers": workers, "h2d_chunk_envs": 128}
+    h = torch.empty((n, 2, 210, 160, 3), dtype=torch.uint8).pin_memory()
+    d = torch.empty_like(h, device=dev)
+    for _ in range(2):
+        d.copy_(h, non_blocking=True)
+    torch.cuda.synchronize(dev)
     t0 = time.perf_counter()
-    reps = 0
-    while time.perf_counter() - t0 < budget_s:
-        ring.ingest(frames, np.full(n, 2))
-        full = ring.full_state()
-        for i in range(n):
-            fov[i].step(full[i], acts[i])
-        reps += 1
-    el = time.perf_counter() - t0
-    return {"value": n * reps / el, "unit": "env steps/s", "cores": 1, "kind": "port",
-            "sample": f"{n} envs x {reps} steps of the same config through oracle/oracle.py (NumPy, single thread), {el:.1f} s"}
+    for _ in range(5):
+        d.copy_(h, non_blocking=True)
+    torch.cuda.synchronize(dev)
+    out["h2d_GBps"] = h.numel() * 5 / (time.perf_counter() - t0) / 1e9
+    del h, d
+    act = {"motor_action": np.zeros(n, np.int64), "sensory_action": np.full((n, 2), 20.0, np.float32)}
+    for fmt, steps in (("rgb", 12), ("gray", 24)):
+        args = AtariEnvArgs(frame_format=fmt, game="breakout", seed=1, obs_size=(84, 84), fov_size=(30, 30), fov_init_loc=(0, 0),
+                            sensory_action_mode="absolute", resize_to_full=True, frame_source="native", device=str(dev),
+                            num_workers=workers, h2d_chunk_envs=128)
+        env = AtariVecEnv(args, n, kind="fixed")
+        env.reset()
+        env.step(act)
+        best = None
+        for _ in range(2):
+            torch.cuda.synchronize(dev)
+            t0 = time.perf_counter()
+            for _ in range(steps):
+                env.step(act)
+            torch.cuda.synchronize(dev)
+            dt = (time.perf_counter() - t0) / steps
+            best = dt if best is None else min(best, dt)
+        env.close()
+        bytes_step = n * 2 * 210 * 160 * (3 if fmt == "rgb" else 1)
+        out[fmt] = {"ms_per_step": best * 1e3, "env_steps_per_s": n / best, "h2d_bytes_per_step": bytes_step,
+                    "pcie_GBps_effective": bytes_step / best / 1e9, "steps_timed": steps}
+    return out
 
 
 def pmc_traffic(kernel, n_envs, kind):
-    """HBM bytes per launch of `kernel` from the committed PMC profile (profiles/r*_traffic.json: FETCH_SIZE and
+    """HBM bytes per launch of `kernel` from the committed PMC profile (profiles/r*_traffic*.json: FETCH_SIZE and
     WRITE_SIZE collected in separate rocprofv3 --pmc passes of this same command by tools/traffic.sh, FETCH_SIZE
     x2 as MI355X_MICROARCH.md prescribes for gfx950 - the factor re-measured on 12 B/lane and 16 B/lane reads of a
     known byte count).  Counters cannot be read from inside the process, so this is the profile's number, quoted
-    only for the configuration it was collected on; otherwise None."""
+    only for the configuration it was collected on AND only when the profile was collected on the very build that is
+    running (agx_build_info(): a hash of the kernel sources); otherwise None, with the reason."""
     import glob
-    if n_envs != 1024 or kind != "fixed":
-        return None
-    files = sorted(glob.glob(os.path.join(REPO, "profiles", "r*_traffic.json")))
-    if not files:
-        return None
-    try:
-        prof = json.load(open(files[-1]))
-        e = prof["kernels"][kernel]
-        return {"traffic": float(e["traffic"]),
-                "note": f"{os.path.relpath(files[-1], REPO)}: FETCH_SIZE x {e['fetch_factor_used']:.3f} + WRITE_SIZE, separate --pmc passes"}
-    except (KeyError, ValueError, OSError):
-        return None
+    from active_gym import _native as nat
+    if n_envs != 1024:
+        return None, "profile exists for 1024 envs per GPU only"
+    files = sorted(glob.glob(os.path.join(REPO, "profiles", "r*_traffic*.json")))
+    why = "no profiles/r*_traffic*.json"
+    for f in reversed(files):
+        try:
+            prof = json.load(open(f))
+            e = prof["kernels"][kernel]
+            if prof.get("build") != nat.build_info():
+                why = f"{os.path.relpath(f, REPO)} was collected on '{prof.get('build')}', this library is '{nat.build_info()}': stale, not quoted"
+                continue
+            return {"traffic": float(e["traffic"]),
+                    "note": f"{os.path.relpath(f, REPO)} ({e.get('kernel_name', kernel)}; build {prof['build']}): FETCH_SIZE x "
+                            f"{e['fetch_factor_used']:.3f} + WRITE_SIZE, separate --pmc passes"}, None
+        except (KeyError, ValueError, OSError, TypeError):
+            continue
+    return None, why
 
 
 def barrier(dist, local_rank):
@@ -194,6 +328,17 @@ def max_over_ranks(value, dist, device):
     t = torch.tensor([value], dtype=torch.float64, device=device if dist.get_backend() == "nccl" else "cpu")
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
     return float(t.item())
+
+
+def all_ranks(value, dist, device):
+    """Every rank's scalar, in rank order (a one-element list for a single process)."""
+    if dist is None or not dist.is_initialized():
+        return [float(value)]
+    import torch
+    t = torch.tensor([value], dtype=torch.float64, device=device if dist.get_backend() == "nccl" else "cpu")
+    out = [torch.zeros_like(t) for _ in range(dist.get_world_size())]
+    dist.all_gather(out, t)
+    return [float(x.item()) for x in out]
 
 
 def relaunch_under_torchrun(args):
@@ -303,6 +448,7 @@ def main():
     torch.cuda.synchronize(dev)
     elapsed = time.perf_counter() - t0
     barrier(dist, local_rank)
+    per_rank = all_ranks(elapsed, dist, dev)                 # every rank's own duration of the timed region
     elapsed = max_over_ranks(elapsed, dist, dev)
 
     out = None
@@ -315,6 +461,12 @@ def main():
             t_ing = sum(e[0].elapsed_time(e[1]) for e in ev.values()) / len(ev) * 1e-3
             t_fov = sum((e[2].elapsed_time(e[3]) if kernel_events else e[1].elapsed_time(e[2])) for e in ev.values()) / len(ev) * 1e-3
             b_ing, b_fov = pipe.algorithmic_bytes("ingest_gray_raw" if gray else "ingest"), pipe.algorithmic_bytes("fovea")
+            if args.kind == "flexible":
+                # 4*rh*rw (u8 windows of the 4 stacked frames) + 112,896 B per env, with rh*rw the mean over
+                # the seeded resolution distribution as the envs hold it at the end of the run (the ABI's figure uses the
+                # nominal 30x30 window)
+                win_mean = float((res_out[:, 0].double() * res_out[:, 1].double()).mean().item())
+                b_fov = int(n * pipe.frame_stack * (win_mean + 84 * 84 * 4))
             if fused:
                 fs = pipe.frame_stack
                 plan = (("k_step_fixed (ingest + fovea of the %d untouched ring slots)" % (fs - 1), b_ing + b_fov * (fs - 1) // fs, t_ing),
@@ -331,11 +483,13 @@ def main():
                     "launches_timed": len(ev), "timing": (f"HIP start/stop events stamped by the launch itself (hipExtLaunchKernelGGL) on every {M}th step of the "
                                "timed region, on the launch stream" if kernel_events else
                                f"HIP events recorded on the launch stream around every {M}th step of the timed region")}
-            tr = pmc_traffic(dom, n, args.kind)
+            tr, why = pmc_traffic(dom, n, args.kind)
             if tr is not None:
                 roof["traffic"] = tr["traffic"]
                 roof["traffic_unit"] = "bytes per launch"
                 roof["traffic_source"] = tr["note"]
+            else:
+                roof["traffic_source"] = why
         out = {
             "metric": "env steps/sec at N=1024 AtariFixedFovealEnv; 1/2/4/8-GPU scaling",
             "value": total_envs * K / elapsed, "unit": "env steps/s", "n_gpus": world, "steps": K, "warmup": args.warmup,
@@ -350,8 +504,16 @@ def main():
                                      "step as two stand-alone full-batch launches carrying the roofline's HIP events"
                                      % (os.environ.get("AGX_STEP_SPLIT", "default 2"), M)) if split else "two stand-alone launches per step",
                        "parallelism": f"env-shard x{world}, no collective"},
-            "roofline": roof, "kernels": kernels,
+            "roofline": roof, "kernels": kernels, "build": _build_info(),
+            "per_gpu": [n * K / t_ for t_ in per_rank], "per_gpu_unit": "env steps/s of each rank over its own timed region",
         }
+        if world > 1:
+            out["config"]["games"] = "one synthetic frame source per GPU (the game mix only changes the emulator, never the shapes)"
+        if world == 1 and not args.no_e2e:
+            try:
+                out["e2e"] = run_e2e(dev, n, host_cores())
+            except Exception as ex:  # noqa: BLE001 - a reported extra, never the metric
+                out["e2e"] = {"error": repr(ex)}
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args.cpu_seconds, 1234)
         print(json.dumps(out), flush=True)

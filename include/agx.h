@@ -109,6 +109,11 @@ typedef struct agx_config {
 
 AGX_API int agx_abi_version(void);
 
+/* Identity of the built library: "libagx abi <v> src <12 hex digits>", the digits being a SHA-256 prefix over the
+ * kernel and ABI sources it was compiled from (active-gym_amd/build.py).  Measurement files under profiles/ record it,
+ * and bench.py refuses a PMC traffic figure collected on a different build. */
+AGX_API const char *agx_build_info(void);
+
 /* Validates the configuration (mirrors `assert fov_size < obs_size`,
  * fov_env.py:112), allocates ring / head / fov_loc / fov_res on the device,
  * builds the resize tables.  The ring starts zero-filled, fov_loc = rint(init_loc),

@@ -24,7 +24,7 @@ def _declared():
 
 def test_header_declares_the_expected_surface():
     names = _declared()
-    assert len(names) == 21 and "agx_ingest" in names and "agx_fovea_flexible" in names
+    assert len(names) == 22 and "agx_ingest" in names and "agx_fovea_flexible" in names
 
 
 def test_library_exports_every_declared_symbol():
@@ -42,6 +42,10 @@ def test_binding_matches_header():
     lib = nat.lib()
     assert lib.agx_abi_version() == nat.ABI_VERSION
     assert ctypes.sizeof(nat.AgxConfig) == 96
+    spec = importlib.util.spec_from_file_location("agx_build", os.path.join(REPO, "active-gym_amd", "build.py"))
+    m = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(m)
+    assert nat.build_info() == f"libagx abi 1 src {m.source_hash()}"      # the loaded .so is built from the tree's sources
 
 
 def test_create_fails_loudly_without_gpu_or_bad_config():
