@@ -80,10 +80,8 @@ class AtariEnv(_SingleEnv):
         self.observation_space = Box(low=-1., high=1., shape=(self.frame_stack,) + self.obs_size, dtype=np.float32)
 
     def _rekind(self, kind):
-        """A fovea wrapper re-creates the core with its own kernel kind (before the first reset)."""
-        self._core.close()
-        self._core = AtariVecEnv(self.args, 1, kind=kind, autoreset=False)
-        return self._core
+        """A fovea wrapper switches the core to its own kernel kind (before the first reset); the emulator is kept."""
+        return self._core.rekind(kind)
 
     @property
     def training(self):

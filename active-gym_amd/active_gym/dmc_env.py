@@ -228,7 +228,7 @@ class DMCVecEnv(AtariVecEnv):
         else:
             for i in idx:
                 self._d_frames[int(i)].copy_(self._h_rframes[int(i)], non_blocking=True)
-        self._ev_rcopy.record()
+        self._ev_rcopy.record(torch.cuda.current_stream(self.device))
 
     def _extra_info(self, info):                                                               # dmc_env.py:189-192
         info["internal_state"] = np.stack([np.asarray(s) for s in self.runner.internal_state])
@@ -260,9 +260,7 @@ class DMCEnv(_SingleEnv):
         self._state_space = Box(lo, hi, dtype=np.float32)
 
     def _rekind(self, kind):
-        self._core.close()
-        self._core = DMCVecEnv(self.args, 1, kind=kind, autoreset=False)
-        return self._core
+        return self._core.rekind(kind)
 
     observation_space = property(lambda self: self._observation_space)
     state_space = property(lambda self: self._state_space)

@@ -159,9 +159,16 @@ class FixedFovealEnv(_SingleEnv):
 
     @staticmethod
     def _one(x, cols):
+        # a scalar (what the reference's scalar sensory_action Box samples) is broadcast to every column, as
+        # np.clip(loc, 0, obs - fov) does in the reference (fov_env.py:166-167)
         if isinstance(x, torch.Tensor):
-            return x.detach().reshape(1, cols) if cols else x.detach().reshape(1)
+            x = x.detach()
+            if cols and x.numel() == 1:
+                x = x.reshape(1, 1).expand(1, cols)
+            return x.reshape(1, cols) if cols else x.reshape(1)
         x = np.asarray(x)
+        if cols and x.size == 1:
+            x = np.broadcast_to(x.reshape(1, 1), (1, cols))
         return x.reshape(1, cols) if cols else x.reshape(-1)[:1]
 
     def step(self, action):

@@ -20,6 +20,23 @@ import numpy as np
 RAW_H, RAW_W = 210, 160
 
 
+def resolve_frame_format(args, real=None) -> str:
+    """"rgb" | "gray": which screens travel from the emulators to the device.  An explicit ``args.frame_format`` wins.
+    Default: real emulators (``frame_source`` "ale" / "native:ale") hand over ALE's OWN grayscale screens - exactly what
+    the reference reads (``getScreenGrayscale``, atari_env.py:74): ALE's palette table has done the luminance, a third of
+    the PCIe bytes, and no restated luminance arithmetic on the device.  Everything else (synthetic / scripted sources,
+    factories) defaults to raw RGB screens with the luminance on the GPU, the workload BASELINE.json's metric names."""
+    fmt = getattr(args, "frame_format", None)
+    if fmt is None:
+        if real is None:                         # `real`: the caller already knows whether a real ALE sits behind it
+            src = getattr(args, "frame_source", "ale")
+            real = isinstance(src, str) and src in ("ale", "native:ale")
+        fmt = "gray" if real else "rgb"
+    if fmt not in ("rgb", "gray"):
+        raise ValueError("frame_format must be 'rgb' (getScreenRGB, luminance on the device) or 'gray' (getScreenGrayscale)")
+    return fmt
+
+
 class SyntheticALE:
     """Procedural 210x160 RGB screens with the ALE call surface."""
 
@@ -30,7 +47,10 @@ class SyntheticALE:
         self.start_lives = start_lives
         self.max_frames = max_frames
         self._rng = np.random.default_rng(self._seed)
-        pal = np.random.default_rng(hash(game) & 0xFFFF).integers(0, 256, size=(16, 3), dtype=np.uint8)
+        import zlib
+        # a stable hash of the game name: Python's str hash is salted per process, and the ranks of a sharded run must
+        # agree on the palette
+        pal = np.random.default_rng(zlib.crc32(str(game).encode()) & 0xFFFF).integers(0, 256, size=(16, 3), dtype=np.uint8)
         self._palette = pal
         self._screen = np.zeros((RAW_H, RAW_W, 3), np.uint8)
         self.reset_game()

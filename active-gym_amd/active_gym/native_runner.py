@@ -12,7 +12,7 @@ from typing import Callable, Optional, Sequence
 import numpy as np
 
 from . import _native as nat
-from .frame_source import RAW_H, RAW_W
+from .frame_source import RAW_H, RAW_W, resolve_frame_format
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(os.path.dirname(_HERE), "lib", "libagx_runner.so")
@@ -72,11 +72,15 @@ def _find_libale_c():
 
 class NativeHostRunner:
     def __init__(self, args, num_envs: int, frames: Optional[np.ndarray] = None, workers: Optional[int] = None,
-                 noop_fn: Optional[Callable[[], int]] = None, env_offset: int = 0, backend: str = "scripted"):
+                 noop_fn: Optional[Callable[[], int]] = None, env_offset: int = 0, backend: str = "scripted",
+                 noop_per_env: bool = False):
         self._lib = lib()
         self.args = args
         self.num_envs = int(num_envs)
         self.noop_fn = noop_fn or (lambda: random.randrange(30))       # reference atari_env.py:96
+        from .runner import per_env_noop_seed
+        self._noop_rngs = ([random.Random(per_env_noop_seed(args.seed, int(env_offset) + i)) for i in range(self.num_envs)]
+                           if noop_per_env and noop_fn is None else None)      # see AtariHostRunner
         cfg = AgxrConfig()
         cfg.struct_size = C.sizeof(AgxrConfig)
         cfg.num_envs, cfg.env_offset = self.num_envs, int(env_offset)
@@ -88,7 +92,7 @@ class NativeHostRunner:
         cfg.scripted_lives = int(getattr(args, "scripted_lives", 3))
         cfg.scripted_p_life = int(getattr(args, "scripted_p_life", 4))
         cfg.scripted_p_over = int(getattr(args, "scripted_p_over", 1))
-        self.gray = getattr(args, "frame_format", "rgb") == "gray"
+        self.gray = resolve_frame_format(args, real=(backend == "ale_c")) == "gray"
         cfg.gray_frames = int(self.gray)
         cfg.backend = backend.encode()
         if backend == "ale_c":
@@ -176,7 +180,8 @@ class NativeHostRunner:
         idx = np.arange(self.num_envs, dtype=np.int32) if idx is None else np.asarray(list(idx), dtype=np.int32)
         lt = self.life_termination
         # no-op counts are drawn here, in env order, only for full resets - like the Python runner
-        noops = np.array([0 if lt[i] else int(self.noop_fn()) for i in idx], dtype=np.int32)
+        noops = np.array([0 if lt[i] else (self._noop_rngs[i].randrange(30) if self._noop_rngs is not None else int(self.noop_fn()))
+                          for i in idx], dtype=np.int32)
         buf = self.frames if out is None else out
         assert buf.dtype == np.uint8 and buf.flags.c_contiguous and buf.shape[0] == self.num_envs
         stride = buf.strides[0]

@@ -26,19 +26,46 @@ from typing import Callable, Optional, Sequence
 import numpy as np
 
 from . import _native as nat
-from .frame_source import RAW_H, RAW_W, make_emulator
+from .frame_source import RAW_H, RAW_W, make_emulator, resolve_frame_format
+
+
+def per_env_noop_seed(seed, global_index: int) -> int:
+    """Seed of env `global_index`'s own no-op stream (noop_per_env), shared by the Python and the native runner."""
+    return (int(seed) * 1000003 + int(global_index)) & 0x7FFFFFFF
+
+
+def check_motor_actions(motor, num_actions: int):
+    """Index into the minimal action set, validated like the native runner does (the reference's `actions.get(a)`
+    yields None for an unknown index and ALE raises, atari_env.py:122-124): no silent wrap-around of -1, no truncation
+    of fractional values."""
+    m = np.asarray(motor)
+    if m.dtype.kind == "f":
+        if not np.all(m == np.floor(m)):
+            raise ValueError("motor_action must be integral")
+    elif m.dtype.kind not in "iub":
+        raise TypeError(f"motor_action dtype {m.dtype} not supported")
+    mi = m.astype(np.int64)
+    if mi.size and (mi.min() < 0 or mi.max() >= num_actions):
+        raise ValueError(f"motor_action out of range [0, {num_actions})")
+    return mi
 
 
 class AtariHostRunner:
     def __init__(self, args, num_envs: int, frames: Optional[np.ndarray] = None,
                  workers: Optional[int] = None, noop_fn: Optional[Callable[[], int]] = None,
-                 env_offset: int = 0):
+                 env_offset: int = 0, noop_per_env: bool = False):
         self.args = args
         self.num_envs = int(num_envs)
         self.action_repeat = int(args.action_repeat)
         self.clip_reward = bool(args.clip_reward)
         self.training = True                    # reference atari_env.py:58: args.training is ignored
         self.noop_fn = noop_fn or (lambda: random.randrange(30))     # reference atari_env.py:96
+        self.env_offset = int(env_offset)
+        # noop_per_env: every env draws its no-op counts from a stream of its own, seeded by (args.seed, GLOBAL env
+        # index), instead of the process-global `random` the reference uses - what makes a sharded run reproduce the
+        # unsharded one (sharding.py); an explicit noop_fn wins
+        self._noop_rngs = ([random.Random(per_env_noop_seed(args.seed, self.env_offset + i)) for i in range(self.num_envs)]
+                           if noop_per_env and noop_fn is None else None)
         self.emulators = [make_emulator(args, env_offset + i) for i in range(self.num_envs)]
         acts = [list(e.getMinimalActionSet()) for e in self.emulators]
         self.actions = acts                     # index -> emulator action, reference atari_env.py:51-52
@@ -47,7 +74,7 @@ class AtariHostRunner:
         self.life_termination = np.zeros(self.num_envs, bool)
         # frame_format "gray": ALE's own grayscale screens (getScreenGrayscale - what the reference reads,
         # atari_env.py:74) instead of RGB; a third of the bytes, no luminance arithmetic on the device
-        self.gray = getattr(args, "frame_format", "rgb") == "gray"
+        self.gray = resolve_frame_format(args) == "gray"
         shape = (self.num_envs, 2, RAW_H, RAW_W) + (() if self.gray else (3,))
         if frames is None:
             frames = np.zeros(shape, np.uint8)
@@ -88,10 +115,13 @@ class AtariHostRunner:
         for f in futs:
             f.result()
 
+    def _draw_noops(self, i: int) -> int:
+        return self._noop_rngs[i].randrange(30) if self._noop_rngs is not None else int(self.noop_fn())
+
     # ------------------------------------------------------------------ step   (atari_env.py:119-148)
     def step(self, motor_actions) -> tuple:
         n = self.num_envs
-        motor = np.asarray(motor_actions).reshape(n)
+        motor = check_motor_actions(motor_actions, self.num_actions).reshape(n)
         raw = np.zeros(n, np.float64)
         done = np.zeros(n, bool)
         cmd = np.zeros(n, np.uint8)
@@ -133,7 +163,7 @@ class AtariHostRunner:
         idx = list(range(n)) if idx is None else [int(i) for i in idx]
         cmd = np.full(n, nat.CMD_SKIP, np.uint8)
         # no-op counts are drawn on the calling thread, in env order, from the global RNG
-        noops = {i: (0 if self.life_termination[i] else int(self.noop_fn())) for i in idx}
+        noops = {i: (0 if self.life_termination[i] else self._draw_noops(i)) for i in idx}
 
         def one(i):
             e = self.emulators[i]

@@ -36,8 +36,11 @@ def env_rank_world():
 
 
 class ShardedAtariVecEnv:
-    """The local shard of a global batch of `num_envs` envs.  Env i of the global batch keeps its identity
-    (emulator seed = args.seed + i) whatever the world size, so a sharded run reproduces the unsharded one."""
+    """The local shard of a global batch of `num_envs` envs.  Env i of the global batch keeps its identity whatever
+    the world size - emulator seed = args.seed + i, and (``noop_per_env``, on by default here) a no-op reset stream of
+    its own seeded by (args.seed, i) instead of the reference's process-global ``random`` - so a sharded run reproduces
+    ``AtariVecEnv(args, num_envs, noop_per_env=True)`` env for env (tests/test_gpu_sharding.py).  Pass
+    ``noop_per_env=False`` (or a ``noop_fn``) to keep the reference's global stream per process."""
 
     def __init__(self, args, num_envs: int, kind: str = "fixed", rank=None, world_size=None, local_rank=None, **kw):
         import torch
@@ -55,6 +58,7 @@ class ShardedAtariVecEnv:
             args = copy.copy(args)
             args.game = shard_game(args.game, self.rank)
         self.game = getattr(args, "game", None)
+        kw.setdefault("noop_per_env", kw.get("noop_fn") is None)
         self.env = AtariVecEnv(args, self.hi - self.lo, kind=kind, env_offset=self.lo, **kw)
 
     def __getattr__(self, name):

@@ -42,7 +42,8 @@ class AtariVecEnv:
     the reference; a cuda device -> torch tensors that stay in HBM), ``antialias``, ``num_workers``."""
 
     def __init__(self, args, num_envs: int, kind: str = "fixed", env_offset: int = 0, noop_fn=None,
-                 autoreset: bool = True):
+                 autoreset: bool = True, noop_per_env: bool = False):
+        self._noop_per_env = bool(noop_per_env)
         self.autoreset = bool(autoreset)        # False: single-env semantics, the caller calls reset()
         if kind not in _KINDS:
             raise ValueError(f"kind must be one of {_KINDS}")
@@ -61,6 +62,26 @@ class AtariVecEnv:
         if self.device.index is None:
             self.device = torch.device("cuda", torch.cuda.current_device())
 
+        self._build_pipeline()
+        self._setup_source(args, noop_fn, env_offset)
+        self._build_spaces()
+
+    def rekind(self, kind: str):
+        """Swap the wrapper kind before the first reset, keeping the host runner and its emulators (the single-env fovea
+        wrappers build on the base env's core: one ALE / MuJoCo construction per env, not two)."""
+        if kind not in _KINDS:
+            raise ValueError(f"kind must be one of {_KINDS}")
+        if self._was_reset:
+            raise RuntimeError("rekind() after reset()")
+        if kind != self.kind:
+            self.pipe.close()
+            self.kind = kind
+            self._build_pipeline()
+            self._build_spaces()
+        return self
+
+    def _build_pipeline(self):
+        args, kind = self.args, self.kind
         kw = dict(num_envs=self.num_envs, kind=kind, obs_size=self.obs_size, frame_stack=self.frame_stack,
                   device=self.device)
         if kind != "base":
@@ -88,8 +109,8 @@ class AtariVecEnv:
             self.mask_out, self.resize_to_full = mask_out, resize_to_full
         self.pipe = ObsPipeline(**kw)
 
-        self._setup_source(args, noop_fn, env_offset)
-
+    def _build_spaces(self):
+        kind = self.kind
         # spaces (reference atari_env.py:69-70, fov_env.py:125-142,243)
         self.single_motor_space = self._motor_space()
         full = (self.frame_stack,) + self.obs_size
@@ -139,9 +160,8 @@ class AtariVecEnv:
 
     def _setup_source(self, args, noop_fn, env_offset):
         # host side: pinned staging for step frames and for reset frames, device twins
-        fmt = getattr(args, "frame_format", "rgb")
-        if fmt not in ("rgb", "gray"):
-            raise ValueError("frame_format must be 'rgb' (getScreenRGB, luminance on the device) or 'gray' (getScreenGrayscale)")
+        from .frame_source import resolve_frame_format
+        fmt = resolve_frame_format(args)         # real emulators default to ALE's own grayscale screens (atari_env.py:74)
         self._gray = fmt == "gray"
         px = () if self._gray else (3,)
         shape = (self.num_envs, 2, nat.RAW_H, nat.RAW_W) + px
@@ -162,11 +182,12 @@ class AtariVecEnv:
             from .native_runner import NativeHostRunner
             self.runner = NativeHostRunner(args, self.num_envs, frames=self._h_frames.numpy(),
                                            workers=getattr(args, "num_workers", None), noop_fn=noop_fn,
-                                           env_offset=env_offset, backend="ale_c" if src == "native:ale" else "scripted")
+                                           env_offset=env_offset, backend="ale_c" if src == "native:ale" else "scripted",
+                                           noop_per_env=self._noop_per_env)
         else:
             self.runner = AtariHostRunner(args, self.num_envs, frames=self._h_frames.numpy(),
                                           workers=getattr(args, "num_workers", None), noop_fn=noop_fn,
-                                          env_offset=env_offset)
+                                          env_offset=env_offset, noop_per_env=self._noop_per_env)
 
     # ------------------------------------------------------------------ plumbing
     def close(self):
@@ -192,7 +213,7 @@ class AtariVecEnv:
         self._h_cmd.numpy()[:] = cmd
         self._d_cmd.copy_(self._h_cmd, non_blocking=True)
         self._d_frames.copy_(self._h_frames, non_blocking=True)
-        self._ev_copy.record()
+        self._ev_copy.record(torch.cuda.current_stream(self.device))
 
     def _upload_reset(self, cmd: np.ndarray, idx):
         """H2D of the reset screens of the envs in `idx` (slot 0 only) and their command bytes."""
@@ -203,7 +224,7 @@ class AtariVecEnv:
         else:
             for i in idx:
                 self._d_frames[int(i), 0].copy_(self._h_rframes[int(i), 0], non_blocking=True)
-        self._ev_rcopy.record()
+        self._ev_rcopy.record(torch.cuda.current_stream(self.device))
 
     def _as_device_action(self, a, cols):
         if isinstance(a, torch.Tensor):
@@ -214,7 +235,12 @@ class AtariVecEnv:
             t = t.float()
         if t.dtype in (torch.int8, torch.int16, torch.uint8, torch.bool):
             t = t.to(torch.int32)
-        t = t.reshape(self.num_envs, cols) if cols else t.reshape(self.num_envs)
+        n = self.num_envs
+        if cols and t.numel() in (n, 1) and t.numel() != n * cols:
+            # the reference's sensory_action space is a SCALAR Box (fov_env.py:125-129): `action_space.sample()` gives one
+            # number per env, which `np.clip(loc, 0, obs - fov)` broadcasts to (a, a) (fov_env.py:166-167)
+            t = t.reshape(-1, 1).expand(n, cols)
+        t = t.reshape(n, cols) if cols else t.reshape(n)
         return t.to(self.device, non_blocking=True).contiguous()
 
     def _observe(self, action=None, action_type=None, mask=None, out=None):
@@ -290,7 +316,7 @@ class AtariVecEnv:
             reward, done, cmd, raw = self.runner.step_finish()
             self._h_cmd.numpy()[:] = cmd
             self._d_cmd.copy_(self._h_cmd, non_blocking=True)
-            self._ev_copy.record()
+            self._ev_copy.record(torch.cuda.current_stream(self.device))
         else:
             reward, done, cmd, raw = self.runner.step(motor)
             self._upload(cmd)

@@ -368,3 +368,48 @@ def test_config1_single_env_10k_steps_against_cpu_reference_path():
     assert worst <= TOL, worst
     assert episodes >= 20 and 0 < life_resets < episodes          # both reset paths were exercised
     env.close()
+
+
+@pytest.mark.parametrize("factory,mode", [("AtariFixedFovealEnv", "absolute"), ("AtariFixedFovealEnv", "relative"),
+                                          ("AtariFlexibleFovealEnv", "absolute"), ("AtariFixedFovealPeripheralEnv", "relative")])
+def test_readme_quickstart_action_space_sample_steps(factory, mode):
+    """`env.step(env.action_space.sample())` (reference README.md:40-50): the sensory_action Box is SCALAR, as the
+    reference declares it (fov_env.py:125-129), so a sample is one number, which np.clip(loc, 0, obs - fov) broadcasts to
+    (a, a) (fov_env.py:166-167,193-199).  Single envs and the batched env (one number per env)."""
+    import active_gym
+    from active_gym import AtariVecEnv
+    kw = dict(fov_size=(30, 30), fov_init_loc=(10, 20), sensory_action_mode=mode, sensory_action_space=(-6.0, 6.0),
+              resize_to_full=True, peripheral_res=(20, 20))
+    env = getattr(active_gym, factory)(_args(**kw))
+    env.action_space.seed(3)
+    env.reset()
+    loc = np.array([10, 20])
+    for _ in range(8):
+        a = env.action_space.sample()
+        assert np.asarray(a["sensory_action"]).shape == ()
+        if "sensory_action_type" in a:
+            a["sensory_action_type"] = 0                                     # FOV_LOC: the rule below
+        obs, r, d, t, info = env.step(a)
+        s = float(a["sensory_action"])
+        if mode == "absolute":
+            loc = np.rint(np.clip(np.array([s, s]), 0, 54)).astype(int)
+        else:
+            loc = np.rint(np.clip(loc + np.rint(np.clip(np.array([s, s]), -6, 6)).astype(int), 0, 54)).astype(int)
+        assert np.array_equal(info["fov_loc"], loc) and obs.shape == (4, 84, 84)
+        if d:
+            env.reset()
+            loc = np.array([10, 20])
+    env.close()
+    if factory == "AtariFixedFovealEnv":
+        N = 5
+        venv = AtariVecEnv(_args(**kw), N, kind="fixed")
+        venv.action_space.seed(5)
+        venv.reset()
+        a = venv.action_space.sample()
+        assert np.asarray(a["sensory_action"]).shape == (N,)
+        _, _, _, _, info = venv.step(a)
+        s = np.asarray(a["sensory_action"], dtype=np.float64)[:, None].repeat(2, 1)
+        want = (np.rint(np.clip(s, 0, 54)) if mode == "absolute" else
+                np.rint(np.clip(np.array([10, 20]) + np.rint(np.clip(s, -6, 6)), 0, 54))).astype(int)
+        assert np.array_equal(info["fov_loc"], want)
+        venv.close()

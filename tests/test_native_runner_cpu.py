@@ -134,6 +134,10 @@ def test_ale_c_backend_through_a_stand_in_libale(tmp_path, monkeypatch):
     monkeypatch.setattr(nr, "_find_libale_c", lambda: (so, fake))
     N = 4
     common = dict(game="pong", seed=31, action_repeat=4, clip_reward=False, max_episode_length=108e3)
+    dflt = nr.NativeHostRunner(_Args(**common), 1, backend="ale_c")
+    assert dflt.gray and dflt.frames.shape == (1, 2, 210, 160)        # real ALE: its own grayscale screens by default (atari_env.py:74)
+    dflt.close()
+    common["frame_format"] = "rgb"                                    # the comparison below is on RGB screens
     nv = nr.NativeHostRunner(_Args(**common), N, workers=2, noop_fn=lambda: 4, backend="ale_c")
 
     class _ALE(LcgALE):                                  # same script, libale's action set
