@@ -407,9 +407,10 @@ def test_readme_quickstart_action_space_sample_steps(factory, mode):
         venv.reset()
         a = venv.action_space.sample()
         assert np.asarray(a["sensory_action"]).shape == (N,)
-        _, _, _, _, info = venv.step(a)
+        _, _, done, _, info = venv.step(a)
         s = np.asarray(a["sensory_action"], dtype=np.float64)[:, None].repeat(2, 1)
         want = (np.rint(np.clip(s, 0, 54)) if mode == "absolute" else
                 np.rint(np.clip(np.array([10, 20]) + np.rint(np.clip(s, -6, 6)), 0, 54))).astype(int)
+        want[done] = (10, 20)                                                   # autoreset re-initialises fov_loc (fov_env.py:156-160)
         assert np.array_equal(info["fov_loc"], want)
         venv.close()
