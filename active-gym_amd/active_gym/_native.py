@@ -58,6 +58,7 @@ SIGNATURES = {
     "agx_step_fixed": (C.c_int, [_P, _P, _P, _P, C.c_int, _P, _P, _P, _P]),
     "agx_fovea_peripheral": (C.c_int, [_P, _P, C.c_int, _P, _P, _P, _P]),
     "agx_fovea_flexible": (C.c_int, [_P, _P, C.c_int, _P, _P, _P, _P, _P, _P]),
+    "agx_fovea_flexible_packed": (C.c_int, [_P, _P, C.c_int, _P, _P, C.c_int64, _P, _P, _P, _P]),
 }
 
 _lib = None

@@ -49,6 +49,8 @@ class _SingleEnv:
         for k in keys:
             if k in infos:
                 v = infos[k][0]
+                if hasattr(v, "detach"):                      # device outputs: a torch tensor row
+                    v = v.detach().cpu().numpy()
                 out[k] = v.copy() if isinstance(v, np.ndarray) else (v.item() if hasattr(v, "item") else v)
         return out
 

@@ -194,6 +194,8 @@ class FlexibleFovealEnv(FixedFovealEnv):
     _INFO_KEYS = ("raw_reward", "reward", "ep_len", "fov_loc", "fov_res")
 
     def __init__(self, env, args):
+        if not (getattr(args, "mask_out", False) or getattr(args, "resize_to_full", False)):
+            args.ragged_obs = "packed"                           # single env, raw crops: return the ragged view itself
         super().__init__(env, args)
         self.action_space["sensory_action_type"] = Discrete(len(FlexibleFovealEnvActionType))
         self.fov_init_res = tuple(args.fov_size)
@@ -204,11 +206,9 @@ class FlexibleFovealEnv(FixedFovealEnv):
         self.fov_res = info["fov_res"]
 
     def _obs(self, obs, info):
-        o = obs[0]
-        if not (self.mask_out or self.resize_to_full):          # raw crop is ragged (fov_env.py:283-298)
-            rh, rw = (int(v) for v in info["fov_res"])
-            o = o[..., :rh, :rw]
-        return o
+        # raw crops are ragged (fov_env.py:283-298): the core packs them (args.ragged_obs = "packed", set in __init__), so
+        # obs[0] already is the [fs, res_h, res_w] view - no padded buffer to slice
+        return obs[0]
 
     def _action(self, action):
         a = super()._action(action)

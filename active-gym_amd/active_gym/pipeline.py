@@ -209,6 +209,39 @@ class ObsPipeline:
         nat.check(self._lib.agx_set_stack_u8(self._ctx, ps, self._stream()), self._ctx)
 
     # ------------------------------------------------------------------ fovea
+    def fovea_packed(self, action: Optional[torch.Tensor] = None, action_type: Optional[torch.Tensor] = None,
+                     packed: Optional[torch.Tensor] = None, offsets: Optional[torch.Tensor] = None,
+                     loc_out: Optional[torch.Tensor] = None, res_out: Optional[torch.Tensor] = None):
+        """Flexible env, raw-crop mode, ragged crops packed (reference fov_env.py:283-298 returns [fs, rh, rw] per env):
+        returns (packed f32 [capacity], offsets i64 [N+1], fov_loc, fov_res); env n's crops are
+        ``packed[offsets[n]:offsets[n+1]].view(fs, rh, rw)``."""
+        if self.kind != "flexible" or self.out_mode != nat.OUT_RAW:
+            raise RuntimeError("fovea_packed needs kind='flexible' in raw-crop mode (no mask_out, no resize_to_full)")
+        N = self.num_envs
+        pa, dt = None, 0
+        if action is not None:
+            if action.dtype not in _DT:
+                raise TypeError(f"sensory action dtype {action.dtype} not supported (f32/f64/i32/i64)")
+            pa = self._chk(action, (N, 2), None, "action")
+            dt = _DT[action.dtype]
+        pt = self._chk(action_type, (N,), torch.int32, "action_type") if action_type is not None else None
+        if packed is None:
+            packed = torch.empty((N * self.frame_stack * self.obs_size[0] * self.obs_size[1],), dtype=torch.float32, device=self.device)
+        if packed.dtype != torch.float32 or packed.device != self.device or packed.dim() != 1 or not packed.is_contiguous():
+            raise ValueError("packed must be a contiguous 1-D float32 tensor on the pipeline's device")
+        if offsets is None:
+            offsets = torch.empty((N + 1,), dtype=torch.int64, device=self.device)
+        pof = self._chk(offsets, (N + 1,), torch.int64, "offsets")
+        if loc_out is None:
+            loc_out = torch.empty((N, 2), dtype=torch.int32, device=self.device)
+        if res_out is None:
+            res_out = torch.empty((N, 2), dtype=torch.int32, device=self.device)
+        pl = self._chk(loc_out, (N, 2), torch.int32, "loc_out")
+        pr = self._chk(res_out, (N, 2), torch.int32, "res_out")
+        nat.check(self._lib.agx_fovea_flexible_packed(self._ctx, pa, dt, pt, C.c_void_p(packed.data_ptr()), packed.numel(), pof, pl,
+                                                      pr, self._stream()), self._ctx)
+        return packed, offsets, loc_out, res_out
+
     def fovea_reset(self, mask: Optional[torch.Tensor] = None):
         pm = self._chk(mask, (self.num_envs,), torch.uint8, "mask") if mask is not None else None
         nat.check(self._lib.agx_fovea_reset(self._ctx, pm, self._stream()), self._ctx)

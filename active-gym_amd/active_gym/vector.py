@@ -134,8 +134,23 @@ class AtariVecEnv:
         # RecordWrapper bookkeeping (fov_env.py:29-32,58-63)
         self.cumulative_reward = np.zeros(self.num_envs, np.float64)
         self.ep_len = np.zeros(self.num_envs, np.int64)
-        self._obs = torch.empty(self.pipe.obs_shape if kind != "base" else self.pipe.full_shape,
-                                dtype=torch.float32, device=self.device)
+        # Device-tensor outputs are double-buffered: step() returns buffer t % 2, so an observation stays valid until the
+        # step after next without a 115 MB clone per step (args.copy_obs=True restores a fresh tensor per call)
+        shp = self.pipe.obs_shape if kind != "base" else self.pipe.full_shape
+        self._copy_obs = bool(getattr(self.args, "copy_obs", False))
+        self._obs_bufs = [torch.empty(shp, dtype=torch.float32, device=self.device)
+                          for _ in range(1 if (self._numpy_out or self._copy_obs) else 2)]
+        self._obs_i = 0
+        self._obs = self._obs_bufs[0]
+        # flexible env, raw-crop mode: args.ragged_obs = "packed" returns the ragged crops themselves - a list of N
+        # arrays [fs, res_h, res_w] (views into one packed device buffer), what the reference's env returns per env
+        # (fov_env.py:283-298) - instead of the zero-padded [N, fs, obs_h, obs_w] batch
+        self._ragged_packed = (kind == "flexible" and not (self.mask_out or self.resize_to_full)
+                               and getattr(self.args, "ragged_obs", "padded") == "packed")
+        if self._ragged_packed:
+            self._packed = torch.empty((self.num_envs * self.frame_stack * self.obs_size[0] * self.obs_size[1],),
+                                       dtype=torch.float32, device=self.device)
+            self._poff = torch.zeros((self.num_envs + 1,), dtype=torch.int64, device=self.device)
         self._loc = torch.zeros((self.num_envs, 2), dtype=torch.int32, device=self.device)
         self._res = torch.zeros((self.num_envs, 2), dtype=torch.int32, device=self.device)
         self._was_reset = False
@@ -247,6 +262,10 @@ class AtariVecEnv:
         out = self._obs if out is None else out
         if self.kind == "base":
             self.pipe.observe_full(out)
+        elif self.kind == "flexible" and self._ragged_packed:
+            # no mask in the packed layout: every env is re-observed; an env without an action keeps its state
+            self.pipe.fovea_packed(action, action_type=action_type, packed=self._packed, offsets=self._poff,
+                                   loc_out=self._loc, res_out=self._res)
         elif self.kind == "flexible":
             self.pipe.fovea(action, action_type=action_type, mask=mask, out=out, loc_out=self._loc, res_out=self._res)
         else:
@@ -256,13 +275,37 @@ class AtariVecEnv:
     def _out(self, t: torch.Tensor):
         return t.cpu().numpy() if self._numpy_out else t
 
+    def _next_obs_buffer(self):
+        self._obs_i = (self._obs_i + 1) % len(self._obs_bufs)
+        self._obs = self._obs_bufs[self._obs_i]
+
+    def _ret_obs(self, obs):
+        if self._ragged_packed:
+            off = self._poff.cpu().numpy()
+            res = self._res.cpu().numpy()
+            flat = self._packed[:int(off[-1])]
+            flat = flat.cpu().numpy() if self._numpy_out else (flat.clone() if self._copy_obs else flat)
+            return [flat[int(off[i]):int(off[i + 1])].reshape(self.frame_stack, int(res[i, 0]), int(res[i, 1]))
+                    for i in range(self.num_envs)]
+        if self._numpy_out:
+            return self._out(obs)
+        return obs.clone() if self._copy_obs else obs
+
     def _info(self, raw_reward):
         info = {"raw_reward": np.asarray(raw_reward, dtype=np.float64).copy(),
                 "reward": self.cumulative_reward.copy(), "ep_len": self.ep_len.copy()}
         if self.kind != "base":
-            info["fov_loc"] = self._loc.cpu().numpy().astype(np.int64)
-            if self.kind == "flexible":
-                info["fov_res"] = self._res.cpu().numpy().astype(np.int64)
+            # host outputs: NumPy int64 like the reference's info["fov_loc"].  Device outputs (args.device set): int64
+            # DEVICE tensors - no device-to-host copy, hence no synchronisation inside step(): the next step's emulation
+            # then overlaps this step's last H2D chunk and kernels
+            if self._numpy_out:
+                info["fov_loc"] = self._loc.cpu().numpy().astype(np.int64)
+                if self.kind == "flexible":
+                    info["fov_res"] = self._res.cpu().numpy().astype(np.int64)
+            else:
+                info["fov_loc"] = self._loc.to(torch.int64)
+                if self.kind == "flexible":
+                    info["fov_res"] = self._res.to(torch.int64)
         return self._extra_info(info)
 
     @staticmethod
@@ -287,8 +330,7 @@ class AtariVecEnv:
             self.pipe.fovea_reset()
         obs = self._observe()
         self._was_reset = True
-        return self._out(obs.clone() if not self._numpy_out else obs), self._with_masks(self._info(np.zeros(self.num_envs)),
-                                                                                       self.num_envs)
+        return self._ret_obs(obs), self._with_masks(self._info(np.zeros(self.num_envs)), self.num_envs)
 
     def step(self, action):
         if not self._was_reset:
@@ -305,6 +347,7 @@ class AtariVecEnv:
         if isinstance(motor, torch.Tensor):
             motor = motor.detach().cpu().numpy()
         self._ev_copy.synchronize()             # the previous step's screens have left the pinned buffer
+        self._next_obs_buffer()
         chunk = int(getattr(self.args, "h2d_chunk_envs", 0) or 0)
         if chunk > 0 and hasattr(self.runner, "step_begin"):
             # native runner: chunk c's screens cross PCIe while chunk c+1 is still emulating
@@ -329,13 +372,17 @@ class AtariVecEnv:
         infos = self._with_masks(info, n)
         if self.autoreset and done.any():
             idx = np.nonzero(done)[0]
-            final_obs_t = obs[torch.from_numpy(idx).to(self.device)].clone()
             final_obs = np.empty(n, dtype=object)
             final_info = np.empty(n, dtype=object)
-            fo = self._out(final_obs_t)
+            if self._ragged_packed:
+                cur = self._ret_obs(obs)
+                fo = [cur[i].copy() if isinstance(cur[i], np.ndarray) else cur[i].clone() for i in idx]
+            else:
+                fo = self._out(obs[torch.from_numpy(idx).to(self.device)].clone())
             for k, i in enumerate(idx):
                 final_obs[i] = fo[k]
-                final_info[i] = {key: (val[i].copy() if isinstance(val[i], np.ndarray) else val[i])
+                final_info[i] = {key: (val[i].copy() if isinstance(val[i], np.ndarray) else
+                                       (val[i].clone() if isinstance(val[i], torch.Tensor) else val[i]))
                                  for key, val in info.items()}
             # env.reset() of the done envs inside the same step (SyncVectorEnv, gymnasium<1.0)
             self._ev_rcopy.synchronize()
@@ -352,13 +399,15 @@ class AtariVecEnv:
                 self._observe(None, None, mask=mask)
             rinfo = self._info(np.zeros(n))
             for key in info:
-                infos[key] = np.where(done.reshape((n,) + (1,) * (info[key].ndim - 1)), rinfo[key], info[key])
+                if isinstance(info[key], torch.Tensor):
+                    infos[key] = torch.where(mask.bool().reshape((n,) + (1,) * (info[key].ndim - 1)), rinfo[key], info[key])
+                else:
+                    infos[key] = np.where(done.reshape((n,) + (1,) * (info[key].ndim - 1)), rinfo[key], info[key])
             infos["final_observation"] = final_obs
             infos["_final_observation"] = done.copy()
             infos["final_info"] = final_info
             infos["_final_info"] = done.copy()
-        out = self._out(obs if self._numpy_out else obs.clone())
-        return out, reward, done, truncated, infos
+        return self._ret_obs(obs), reward, done, truncated, infos
 
     def reset_envs(self, idx):
         """Reset only the envs in `idx` (what a caller without autoreset does after `done`)."""
@@ -379,7 +428,7 @@ class AtariVecEnv:
             self.pipe.fovea_reset(mask)
             obs = self._observe(None, None, mask=mask)
         self._was_reset = True
-        return self._out(obs if self._numpy_out else obs.clone()), self._with_masks(self._info(np.zeros(n)), n)
+        return self._ret_obs(obs), self._with_masks(self._info(np.zeros(n)), n)
 
     def render(self, index=0):
         return self.runner.render(index)

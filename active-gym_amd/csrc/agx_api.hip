@@ -42,6 +42,7 @@ struct agx_ctx {
     // K4 resize_to_full form (k_fovea_flexible3): composed per-axis operators, see agx_k4_flex3.h
     Flex3Params f3{};
     bool f3_ok = false;
+    int64_t *pack_sizes = nullptr;   // agx_fovea_flexible_packed: [N] crop sizes (allocated on first use)
     // K3 tuned form 3 (k_fovea_peripheral3)
     Per3Params p3{};
     int p3_mt = 0;
@@ -874,6 +875,9 @@ static FovParams fov_params(agx_ctx *ctx, const void *d_action, int dt, const in
     p.buf1_floats = (int32_t)generic_buf1(c);
     p.cmd = nullptr;
     p.phase = 0;
+    p.packed = nullptr;
+    p.packed_off = nullptr;
+    p.packed_cap = 0;
     p.stamps = nullptr;
 #ifdef AGX_STAMPS
     if (const char *e = getenv("AGX_DBG_PTR2")) p.stamps = reinterpret_cast<unsigned long long *>(strtoull(e, nullptr, 0));
@@ -1147,6 +1151,60 @@ int agx_fovea_flexible(agx_ctx *ctx, const void *d_action, int action_dtype, con
         }
         g.oh = c.obs_h; g.ow = c.obs_w; g.fh = c.fov_h; g.fw = c.fov_w;
         AGX_LAUNCH(1, k_fovea_flexible2, dim3(c.frame_stack, c.num_envs), dim3(kThreads), lds2, S(stream), g, p);
+    } else {
+        hipLaunchKernelGGL((k_fovea_generic<AGX_KIND_FLEXIBLE>), dim3(c.frame_stack, c.num_envs), dim3(kThreads),
+                           generic_lds(c), S(stream), gr, p);
+    }
+    AGX_HIP(ctx, hipGetLastError());
+    ctx->cur_fov ^= 1;
+    return AGX_OK;
+}
+
+int agx_fovea_flexible_packed(agx_ctx *ctx, const void *d_action, int action_dtype, const int32_t *d_action_type,
+                              float *d_packed, int64_t capacity_floats, int64_t *d_offsets, int32_t *d_fov_loc,
+                              int32_t *d_fov_res, void *stream) {
+    if (!ctx) return AGX_E_INVALID;
+    const agx_config &c = ctx->cfg;
+    if (c.kind != AGX_KIND_FLEXIBLE || c.out_mode != AGX_OUT_RAW)
+        return fail(ctx, AGX_E_STATE, "agx_fovea_flexible_packed needs a flexible context in raw-crop mode (kind %d, out_mode %d)",
+                    c.kind, c.out_mode);
+    if (!d_packed || !d_offsets || capacity_floats < 0) return fail(ctx, AGX_E_INVALID, "agx_fovea_flexible_packed: null buffer");
+    int rc = check_dt(ctx, d_action, action_dtype);
+    if (rc) return rc;
+    DeviceGuard g(c.device);
+    if (!ctx->pack_sizes) {
+        AGX_HIP(ctx, hipMalloc(reinterpret_cast<void **>(&ctx->pack_sizes), (size_t)c.num_envs * sizeof(int64_t)));
+        ctx->owned.push_back(ctx->pack_sizes);
+    }
+    // launch 1: every env's new fov_loc / fov_res (fov_env.py:300-324) and its crop size; launch 2: offsets
+    FlexStateParams q;
+    q.f = fov_params(ctx, d_action, action_dtype, d_action_type, nullptr, nullptr, d_fov_loc, d_fov_res);
+    q.sizes = ctx->pack_sizes;
+    q.n = c.num_envs;
+    q.oh = c.obs_h;
+    q.ow = c.obs_w;
+    hipLaunchKernelGGL(k_flex_state, dim3((c.num_envs + kThreads - 1) / kThreads), dim3(kThreads), 0, S(stream), q);
+    hipLaunchKernelGGL(k_scan_sizes, dim3(1), dim3(1024), 0, S(stream), ctx->pack_sizes, d_offsets, (int)c.num_envs);
+    AGX_HIP(ctx, hipGetLastError());
+    ctx->cur_fov ^= 1;
+    // launch 3: the crops (squeezed to fov_size and back iff rows > fov rows, fov_env.py:283-287) at their offsets; the
+    // state is final, so the crop kernel runs with no action and writes the same state through
+    FovParams p = fov_params(ctx, nullptr, 0, nullptr, nullptr, d_packed, nullptr, nullptr);
+    p.packed = d_packed;
+    p.packed_off = d_offsets;
+    p.packed_cap = capacity_floats;
+    const GeomR gr{c.obs_h, c.obs_w, c.fov_h, c.fov_w};
+    const size_t lds2 = flex2_lds(c, ctx->flex_tab_floats);
+    if (ctx->tune.generic == 0 && lds2 <= kMaxLds) {
+        FlexParams fp;
+        TabFamily *fam[6] = {&fp.wd, &fp.wb, &fp.wf, &fp.hd, &fp.hb, &fp.hf};
+        for (int k = 0; k < 6; ++k) {
+            fam[k]->ln = ctx->flex_ln[k];
+            fam[k]->w = ctx->flex_w[k];
+            fam[k]->meta = ctx->flex_meta[k];
+        }
+        fp.oh = c.obs_h; fp.ow = c.obs_w; fp.fh = c.fov_h; fp.fw = c.fov_w;
+        AGX_LAUNCH(1, k_fovea_flexible2, dim3(c.frame_stack, c.num_envs), dim3(kThreads), lds2, S(stream), fp, p);
     } else {
         hipLaunchKernelGGL((k_fovea_generic<AGX_KIND_FLEXIBLE>), dim3(c.frame_stack, c.num_envs), dim3(kThreads),
                            generic_lds(c), S(stream), gr, p);

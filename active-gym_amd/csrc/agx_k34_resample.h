@@ -224,6 +224,13 @@ __global__ __launch_bounds__(kThreads) void k_fovea_generic(GeomR g, FovParams p
         }
         return;
     }
+    if (p.packed) {                                             // raw crops, packed: [j][rh][rw] tight
+        const int64_t off = p.packed_off[n], cnt = (int64_t)rh * rw;
+        if (off + (int64_t)p.fs * cnt > p.packed_cap) return;
+        float *dst = p.packed + off + (int64_t)j * cnt;
+        for (int i = tid; i < rh * rw; i += kThreads) dst[i] = cur[i];
+        return;
+    }
     // mask-out paste at (r, c); raw (padded, window at the origin); resize with res == obs (identity)
     const int pr = (p.out_mode == AGX_OUT_MASK) ? r : 0;
     const int pc = (p.out_mode == AGX_OUT_MASK) ? c : 0;
@@ -671,6 +678,25 @@ __global__ __launch_bounds__(kThreads) void k_fovea_flexible2(FlexParams g, FovP
                 }
             }
             store_obs(&out4[q], o);
+        }
+        return;
+    }
+    if (p.packed) {                                             // raw crops, packed: [j][rh][rw] tight
+        const int64_t off = p.packed_off[n], cnt = (int64_t)rh * rw;
+        if (off + (int64_t)p.fs * cnt > p.packed_cap) return;
+        float *dst = p.packed + off + (int64_t)j * cnt;
+        for (int i = tid; i < rh * rw; i += kThreads) {
+            const int y = dv_rw.div(i), x = i - y * rw;
+            float v;
+            if (squeeze) {
+                const int2 lnb = hb.ln[y];
+                const float *wbv = hb.w + y * hb.maxt;
+                v = 0.f;
+                for (int b = 0; b < lnb.y; ++b) v = fmaf(wbv[b], C[(lnb.x + b) * ow + x], v);
+            } else {
+                v = lut[win[y * ow + x]];
+            }
+            dst[i] = v;
         }
         return;
     }

@@ -224,6 +224,17 @@ AGX_API int agx_fovea_flexible(agx_ctx *ctx, const void *d_action, int action_dt
                        const uint8_t *d_mask, float *d_obs, int32_t *d_fov_loc, int32_t *d_fov_res,
                        void *stream);
 
+/* K4, raw-crop mode with the ragged crops PACKED (the reference returns [fs, res_h, res_w] per env, fov_env.py:283-298):
+ * same state update as agx_fovea_flexible, then
+ *   d_offsets i64 [N + 1] out : env n's crops f32 [fs][res_h][res_w] (tight) start at d_packed + d_offsets[n];
+ *                               d_offsets[N] = total floats = sum_n fs * res_h[n] * res_w[n]
+ *   d_packed  f32 [capacity_floats] out; an env whose crops would end past the capacity is not written
+ *                               (d_offsets[N] > capacity_floats tells the caller; N * fs * obs_h * obs_w always fits)
+ * Context: AGX_KIND_FLEXIBLE with AGX_OUT_RAW.  No mask: the layout of every env depends on every resolution. */
+AGX_API int agx_fovea_flexible_packed(agx_ctx *ctx, const void *d_action, int action_dtype, const int32_t *d_action_type,
+                                      float *d_packed, int64_t capacity_floats, int64_t *d_offsets, int32_t *d_fov_loc,
+                                      int32_t *d_fov_res, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

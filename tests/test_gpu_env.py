@@ -233,6 +233,24 @@ def test_device_outputs_and_synthetic_source():
         obs, r, d, t, infos = env.step(a)
     assert obs.is_cuda and float(obs.max()) <= 1.0 and float(obs.min()) >= 0.0 and float(obs.max()) > 0.0
     assert infos["fov_loc"].shape == (16, 2) and (infos["ep_len"] <= 5).all() and (infos["ep_len"] == 5).any()
+    # device outputs: fov_loc stays on the device (int64, no synchronisation inside step); observations are double-buffered
+    assert isinstance(infos["fov_loc"], torch.Tensor) and infos["fov_loc"].is_cuda and infos["fov_loc"].dtype == torch.int64
+    a = {"motor_action": np.zeros(16, np.int64), "sensory_action": torch.full((16, 2), 11.0, device="cuda")}
+    o1, _, d1, _, i1 = env.step(a)
+    keep = o1.clone()
+    o2, _, _, _, _ = env.step(a)
+    assert o2.data_ptr() != o1.data_ptr() and torch.equal(o1, keep)           # the previous observation is still intact
+    o3, _, _, _, _ = env.step(a)
+    assert o3.data_ptr() == o1.data_ptr()                                      # ... until the step after next
+    assert torch.equal(i1["fov_loc"][~torch.from_numpy(d1).cuda()], torch.full((int((~d1).sum()), 2), 11, device="cuda"))
+    env.close()
+    args.copy_obs = True
+    env = AtariVecEnv(args, 4, kind="fixed")
+    env.reset()
+    a = {"motor_action": np.zeros(4, np.int64), "sensory_action": torch.zeros(4, 2, device="cuda")}
+    p1 = env.step(a)[0].data_ptr()
+    keep2 = env.step(a)[0]
+    assert keep2.data_ptr() != p1                                              # copy_obs: a fresh tensor per call
     env.close()
 
 

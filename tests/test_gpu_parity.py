@@ -841,3 +841,78 @@ def test_create_destroy_does_not_leak(dev):
     torch.cuda.synchronize()
     free1, _ = torch.cuda.mem_get_info(dev)
     assert free0 - free1 < 64 << 20, f"leaked {(free0 - free1) >> 20} MiB"
+
+
+# ---------------------------------------------------------------- K4 raw crops, packed (ragged) output
+@pytest.mark.parametrize("name", [n for n in fovea_case_names() if n.startswith("flex_raw")])
+def test_flexible_raw_packed_golden_replay(dev, name):
+    """agx_fovea_flexible_packed against the reference-run goldens: the ragged [fs, rh, rw] crops themselves
+    (fov_env.py:283-298), no padding."""
+    c = load_fovea(name)
+    p = _pipe_for_case(c)
+    states = c["states_u8"]
+    p.set_stack_u8(_t(states[0][None], dev))
+    p.fovea_reset()
+    packed, off, loc, res = p.fovea_packed()
+    fs = c["frame_stack"]
+
+    def view():
+        o, r = off.cpu().numpy(), res.cpu().numpy()[0]
+        assert o[0] == 0 and o[1] == fs * r[0] * r[1]
+        return packed[:int(o[1])].cpu().numpy().reshape(fs, int(r[0]), int(r[1])), r
+    g, r = view()
+    w = c["outs"][0]
+    assert g.shape == w.shape
+    np.testing.assert_allclose(g.astype(np.float64), w.astype(np.float64), rtol=0, atol=FLOAT_TOL)
+    for t in range(c["steps"]):
+        p.set_stack_u8(_t(states[t + 1][None], dev))
+        a = _t(c["actions"][t][None], dev)
+        at = _t(np.array([c["action_types"][t]], np.int32), dev)
+        packed, off, loc, res = p.fovea_packed(a, action_type=at, packed=packed, offsets=off)
+        assert np.array_equal(res.cpu().numpy()[0], c["fov_res"][t + 1]) and np.array_equal(loc.cpu().numpy()[0], c["fov_loc"][t + 1])
+        g, r = view()
+        w = c["outs"][t + 1]
+        assert g.shape == w.shape, (t, g.shape, w.shape)
+        np.testing.assert_allclose(g.astype(np.float64), w.astype(np.float64), rtol=0, atol=FLOAT_TOL)
+        if int(r[0]) <= int(c["fov_size"][0]):
+            assert np.array_equal(g, w.astype(np.float32)), "an unsqueezed crop must be bit-exact"
+
+
+@pytest.mark.parametrize("aa", [False, True])
+@pytest.mark.parametrize("generic", [False, True])
+def test_flexible_packed_equals_padded(dev, aa, generic, monkeypatch):
+    """The packed layout holds exactly the valid [0:rh, 0:rw] part of the padded raw-crop buffer, env after env, and the
+    capacity guard never writes past the buffer."""
+    for k_ in ("AGX_FOVEA_GENERIC", "AGX_FLEX_V2"):
+        monkeypatch.delenv(k_, raising=False)
+    if generic:
+        monkeypatch.setenv("AGX_FOVEA_GENERIC", "1")
+    N, fs = 37, 3
+    kw = dict(num_envs=N, kind="flexible", obs_size=(84, 84), fov_size=(30, 30), frame_stack=fs, fov_init_loc=(3, 4),
+              sensory_action_mode="absolute", antialias=aa)
+    a_, b_ = _pipe(**kw), _pipe(**kw)
+    rng = np.random.default_rng(3 + aa)
+    for step in range(5):
+        st = _t(rng.integers(0, 256, (N, fs, 84, 84), dtype=np.uint8), dev)
+        a_.set_stack_u8(st)
+        b_.set_stack_u8(st)
+        types = rng.integers(0, 2, N).astype(np.int32)
+        act = np.where(types[:, None] == 1, rng.integers(1, 85, (N, 2)), rng.integers(-5, 90, (N, 2))).astype(np.float64)
+        pad, loc_a, res_a = a_.fovea(_t(act, dev), action_type=_t(types, dev))
+        packed, off, loc_b, res_b = b_.fovea_packed(_t(act, dev), action_type=_t(types, dev))
+        assert torch.equal(loc_a, loc_b) and torch.equal(res_a, res_b)
+        o, r = off.cpu().numpy(), res_b.cpu().numpy()
+        assert o[0] == 0 and np.array_equal(np.diff(o), fs * r[:, 0].astype(np.int64) * r[:, 1])
+        flat, pad = packed.cpu().numpy(), pad.cpu().numpy()
+        for i in range(N):
+            got = flat[o[i]:o[i + 1]].reshape(fs, r[i, 0], r[i, 1])
+            assert np.array_equal(got, pad[i, :, :r[i, 0], :r[i, 1]]), (step, i)
+    # capacity guard: a buffer that holds only the first envs; the canary behind it must survive
+    total = int(off.cpu()[-1])
+    cut = int(off.cpu()[N // 2])
+    small = torch.full((cut + 8,), -7.0, dtype=torch.float32, device=dev)
+    _, off2, _, _ = b_.fovea_packed(None, packed=small[:cut])
+    assert int(off2.cpu()[-1]) == total and (small[cut:] == -7.0).all()
+    assert np.array_equal(small[:cut].cpu().numpy(), flat[:cut])
+    a_.close()
+    b_.close()

@@ -36,12 +36,12 @@ def run(env, lo, hi):
         for k in range(hi - lo):
             dig[k] = zlib.crc32(o[k].tobytes() + extra[k].tobytes(), int(dig[k]) & 0xFFFFFFFF)
     obs, info = env.reset()
-    upd(obs, info["fov_loc"])
+    upd(obs, info["fov_loc"].cpu().numpy())
     for t in range(STEPS):
         motor = rng.integers(0, 4, N)
         sens = rng.uniform(-10, 10, (N, 2)).astype(np.float32)
         obs, rew, done, trunc, info = env.step({"motor_action": motor[lo:hi], "sensory_action": sens[lo:hi]})
-        upd(obs, np.concatenate([info["fov_loc"].astype(np.int64), rew[:, None].astype(np.int64), done[:, None].astype(np.int64),
+        upd(obs, np.concatenate([info["fov_loc"].cpu().numpy(), rew[:, None].astype(np.int64), done[:, None].astype(np.int64),
                                  info["ep_len"][:, None].astype(np.int64)], 1))
     return dig
 
