@@ -246,8 +246,9 @@ def run_e2e(dev, n, hc):
     import numpy as np
     import torch
     from active_gym import AtariEnvArgs, AtariVecEnv
-    workers = max(1, min(64, hc["usable"]))
-    out = {"envs": n, "runner": "libagx_runner.so (C++ threads, scripted emulator)", "workers": workers, "h2d_chunk_envs": 128}
+    workers = max(1, min(64, hc["present"]))      # emulator threads (mostly memory-bound screen writes); the job's CPU quota is hc["usable"]
+    out = {"envs": n, "runner": "libagx_runner.so (C++ threads, scripted emulator)", "workers": workers, "h2d_chunk_envs": 128,
+           "host_cores_usable": hc["usable"], "host_cores_present": hc["present"]}
     h = torch.empty((n, 2, 210, 160, 3), dtype=torch.uint8).pin_memory()
     d = torch.empty_like(h, device=dev)
     for _ in range(2):
