@@ -76,6 +76,21 @@ __device__ __forceinline__ uint32_t ale_lum_exact(uint32_t r, uint32_t g, uint32
 }
 
 struct __attribute__((aligned(4))) U3 { uint32_t x, y, z; };
+// one 12-byte piece of a raw screen (4 RGB pixels), nontemporal: the screens are read exactly once, and keeping them out
+// of L2 / Infinity Cache leaves those to the ring (re-read four times) - same box, N=1024: K1 38.2 -> 37.3 us, K2
+// 24.4 -> 24.0 us, step 62.6 -> 61.4 us.  (-DAGX_K1_PLAIN_LOADS restores default-policy loads.)
+__device__ __forceinline__ U3 load_piece(const uint8_t *ptr) {
+#ifndef AGX_K1_PLAIN_LOADS
+    typedef uint32_t u32x3 __attribute__((ext_vector_type(3)));
+    typedef u32x3 u32x3_a4 __attribute__((aligned(4)));
+    const u32x3 v = __builtin_nontemporal_load(reinterpret_cast<const u32x3_a4 *>(ptr));
+    U3 r;
+    r.x = v.x, r.y = v.y, r.z = v.z;
+    return r;
+#else
+    return *reinterpret_cast<const U3 *>(ptr);
+#endif
+}
 
 struct IngestParams {
     const uint8_t *frames;   // [N][2][210][160][3]
@@ -179,8 +194,8 @@ __device__ __forceinline__ void ingest_band(const IngestParams &p, const int ban
             w0[it].x = *reinterpret_cast<const uint32_t *>(fbase + o0);
             w1[it].x = *reinterpret_cast<const uint32_t *>(fbase + o1);
         } else {
-            w0[it] = *reinterpret_cast<const U3 *>(fbase + o0);
-            w1[it] = *reinterpret_cast<const U3 *>(fbase + o1);
+            w0[it] = load_piece(fbase + o0);
+            w1[it] = load_piece(fbase + o1);
         }
     }
     const uint32_t cmd = uniform_load_u8(p.cmd + n);

@@ -91,7 +91,14 @@ __device__ __forceinline__ void fovea_fixed_body(const G g, const FovParams &p, 
     lut[tid] = unit((uint32_t)tid);
     int r, c;
     compute_loc(p, lin, oh - fh, ow - fw, r, c);
-    int j = sl - head;                                                // stack position of this slot
+#ifndef AGX_K2_VECTOR_STATE
+    // workgroup-uniform: scalar registers from here on (window base, output base)
+    r = __builtin_amdgcn_readfirstlane(r);
+    c = __builtin_amdgcn_readfirstlane(c);
+    int j = sl - __builtin_amdgcn_readfirstlane(head);                // stack position of this slot
+#else
+    int j = sl - head;
+#endif
     if (j < 0) j += p.fs;
     if (sl == 0 && tid == 0) {
         p.loc_out[2 * n] = r;

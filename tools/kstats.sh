@@ -2,7 +2,7 @@
 # usage: tools/kstats.sh <outdir> [bench args...] ; rocprofv3 kernel-trace of a short bench run, prints agx kernel durations
 OUT=${1:-gpurun_out/kstats}; shift
 mkdir -p $OUT; export TMPDIR=/tmp
-timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT -- python3 bench.py --steps 100 --warmup 10 --no-cpu-baseline --no-events "$@" > $OUT/run.log 2>&1 || { echo "rocprof run failed"; tail -5 $OUT/run.log; }
+timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT -- python3 bench.py --steps 100 --warmup 10 --no-cpu-baseline --no-e2e --no-events "$@" > $OUT/run.log 2>&1 || { echo "rocprof run failed"; tail -5 $OUT/run.log; }
 python3 - "$OUT" <<'PY'
 import csv, glob, sys, collections
 d=collections.defaultdict(list); meta={}

@@ -4,7 +4,7 @@ set -u
 OUT=${1:-gpurun_out/pmc}
 mkdir -p $OUT
 export TMPDIR=/tmp
-BENCH="python3 bench.py --steps 40 --warmup 5 --no-cpu-baseline --no-events ${AGX_PMC_BENCH_ARGS:-}"
+BENCH="python3 bench.py --steps 40 --warmup 5 --no-cpu-baseline --no-e2e --no-events ${AGX_PMC_BENCH_ARGS:-}"
 i=0
 for grp in \
   "SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAIT_INST_ANY SQ_ACTIVE_INST_VALU" \
