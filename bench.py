@@ -296,8 +296,9 @@ def pmc_traffic(kernel, n_envs, kind):
     if n_envs != 1024:
         return None, "profile exists for 1024 envs per GPU only"
     files = sorted(glob.glob(os.path.join(REPO, "profiles", "r*_traffic*.json")))
+    files = [f for f in files if not f.endswith(f"_{kind}.json")] + [f for f in files if f.endswith(f"_{kind}.json")]
     why = "no profiles/r*_traffic*.json"
-    for f in reversed(files):
+    for f in reversed(files):                   # newest round first, the file collected under this --kind before the others
         try:
             prof = json.load(open(f))
             e = prof["kernels"][kernel]

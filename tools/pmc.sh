@@ -25,7 +25,7 @@ for f in glob.glob(out+'/p*/**/*counter_collection.csv', recursive=True):
     for r in csv.DictReader(open(f)):
         k=r['Kernel_Name']
         if 'agx::' not in k: continue
-        k=k.split('(')[0][-40:]
+        k=k.split('(')[0].replace('void ','')[:110]
         agg[k][r['Counter_Name']].append(float(r['Counter_Value']))
 with open(out+'/summary.txt','w') as fo:
     for k,d in agg.items():
