@@ -347,6 +347,196 @@ __global__ __launch_bounds__(kThreads) void k_ingest_full12_part(IngestParams p)
     ingest_band<kThreads, false, 12>(p, blockIdx.x, blockIdx.y, smem);
 }
 
+// ---------------------------------------------------------------------------------------------
+// K1, two bands per workgroup with the second band's loads under the first band's tail (opt-in, AGX_INGEST_PAIR12=1:
+// measured a tie with k_ingest_full12): grid = (7 bands, ceil(N / 2)), block = 256.  Workgroup (x, m) ingests band x of env 2m, then band x of env
+// 2m + 1.  A band's life is  [pieces in flight] -> luminance -> barrier -> resize -> ring store; at 8 workgroups per CU
+// (the hardware cap) about a third of it has no load in flight.  Here the second env's 8 pieces per thread are requested
+// as soon as the first env's luminance has consumed its registers, so they fly under the first env's barrier, resize
+// and store: no second register set (the same 24 VGPRs are re-used), a second 7.7 KB gray buffer in LDS, and the two envs
+// share the row offsets and the resize tables (same band).  Bit-identical to k_ingest_full12.
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(kThreads, 8) void k_ingest_pair12(IngestParams p, int n_envs) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    constexpr int T = kThreads, FBR = 12, G4 = kRawW / 4, RG = T / G4, kIter = 4;
+    constexpr uint32_t kRowB = kRawRowBytes, kFrameB = kRawH * kRowB;
+    const int tid = threadIdx.x, band = blockIdx.x, n0 = 2 * blockIdx.y;
+    const bool two = n0 + 1 < n_envs;
+    const int dy0 = band * FBR;
+    int4 *ytab_s = reinterpret_cast<int4 *>(smem);                        // [12]
+    int2 *xtab_s = reinterpret_cast<int2 *>(smem + sizeof(int4) * FBR);   // [ow]
+    unsigned char *gray0 = smem + sizeof(int4) * FBR + sizeof(int2) * p.ow;
+    constexpr uint32_t kGrayB = 2u * FBR * kRawW * 2u;                    // [2 frames][12 rows][160][2]
+    unsigned char *gray1 = gray0 + kGrayB;
+    const int ow4 = p.ow >> 2;
+    const int rg = tid / G4, g4 = tid - rg * G4;
+    const bool loader = rg < RG;
+    const uint32_t col = g4 * 12;
+    // lane offsets of the 8 pieces and their LDS destinations: the same for both envs; recomputed where needed (a handful
+    // of VALU operations) rather than kept alive across the whole kernel
+    auto offsets = [&](int it, uint32_t &a, uint32_t &b) {
+        const int f = it / 2;
+        const int dyl = min(rg + RG * (it - 2 * f), FBR - 1);
+        const int y0 = (int)(mul_u24((uint32_t)(dy0 + dyl), (uint32_t)p.y_mul) + (uint32_t)p.y_add) >> p.y_shift;
+        const int y1 = min(y0 + 1, kRawH - 1);
+        const uint32_t fo = f * kFrameB + col;
+        a = mad_u24((uint32_t)y0, kRowB, fo);
+        b = mad_u24((uint32_t)y1, kRowB, fo);
+    };
+    auto dpos = [&](int it) {
+        const int f = it / 2;
+        const int dyl = min(rg + RG * (it - 2 * f), FBR - 1);
+        return ((f * FBR + dyl) * kRawW + g4 * 4) * 2;
+    };
+    const uint8_t *fb0 = p.frames + (size_t)n0 * 2 * kFrameB;
+    const uint8_t *fb1 = fb0 + (two ? 2 * (size_t)kFrameB : 0);
+    // the resize tables of this band (L2 hits, requested first so that they arrive first and leave their registers for
+    // LDS before the luminance starts), then the first env's 8 pieces
+    const int4 yt_own = p.ytab[dy0 + min(tid, FBR - 1)];
+    const int2 xt_own = p.xtab[min(tid, p.ow - 1)];
+    U3 w0[kIter], w1[kIter];
+#pragma unroll
+    for (int it = 0; it < kIter; ++it) {
+        uint32_t a, b;
+        offsets(it, a, b);
+        w0[it] = load_piece(fb0 + a);
+        w1[it] = load_piece(fb0 + b);
+    }
+    if (tid < FBR) ytab_s[tid] = yt_own;
+    if (tid < p.ow) xtab_s[tid] = xt_own;
+    for (int i = tid + T; i < p.ow; i += T) xtab_s[i] = p.xtab[i];
+    const int nB = __builtin_amdgcn_readfirstlane(n0 + (two ? 1 : 0));
+    const uint32_t cmdA = uniform_load_u8(p.cmd + n0), cmdB = uniform_load_u8(p.cmd + nB);
+    const int headA = uniform_load_i32(p.head_in + n0), headB = uniform_load_i32(p.head_in + nB);
+
+    auto flags = [&](uint32_t cmd, int head, int n, bool &skip, bool &clear, int &nvalid, int &slot) {
+        skip = (cmd & AGX_CMD_SKIP) != 0;
+        clear = (cmd & AGX_CMD_CLEAR) != 0;
+        if (band == 0 && tid == 0) p.head_out[n] = skip ? head : (clear ? 0 : (head + 1 == p.fs ? 0 : head + 1));
+        nvalid = min((int)(cmd & AGX_CMD_NVALID_MASK), 2);
+        slot = clear ? p.fs - 1 : head;
+    };
+    // luminance of the 8 pieces in w0 / w1 -> gray bytes [frame][row][x][2] (the vertical tap pair of a column is one u16)
+    auto luminance = [&](const uint8_t *fbase, unsigned char *gray, int nvalid) {
+        uint32_t tie_its = 0;
+#pragma unroll
+        for (int it = 0; it < kIter; ++it) {
+            uint32_t rmin = 1u;
+            const uint32_t top = lum4_r(w0[it].x, w0[it].y, w0[it].z, rmin);
+            const uint32_t bot = lum4_r(w1[it].x, w1[it].y, w1[it].z, rmin);
+            if (loader && it / 2 < nvalid) {
+                uint2 v;                                                  // t0 b0 t1 b1 | t2 b2 t3 b3
+                v.x = __builtin_amdgcn_perm(bot, top, 0x05010400u);
+                v.y = __builtin_amdgcn_perm(bot, top, 0x07030602u);
+                *reinterpret_cast<uint2 *>(gray + dpos(it)) = v;
+                tie_its |= rmin == 0u ? (1u << it) : 0u;
+            }
+        }
+        if (__builtin_expect(tie_its != 0, 0)) {
+            // an exact .5 tie (about 1e-4 of random pixels): that piece again, byte by byte, with ALE's double expression
+#pragma nounroll
+            for (int it = 0; it < kIter; ++it) {
+                if (!((tie_its >> it) & 1u)) continue;
+                uint32_t oa, ob;
+                offsets(it, oa, ob);
+                unsigned char *g = gray + dpos(it);
+#pragma nounroll
+                for (int which = 0; which < 2; ++which) {                 // row y0, then row y1: bytes g[0,2,4,6] / g[1,3,5,7]
+                    const U3 a = *reinterpret_cast<const U3 *>(fbase + (which ? ob : oa));
+                    const uint32_t px[4] = {a.x, __builtin_amdgcn_alignbyte(a.y, a.x, 3), __builtin_amdgcn_alignbyte(a.z, a.y, 2),
+                                            a.z >> 8};
+#pragma unroll
+                    for (int k = 0; k < 4; ++k)
+                        g[2 * k + which] = (unsigned char)ale_lum_exact(px[k] & 0xFF, (px[k] >> 8) & 0xFF, (px[k] >> 16) & 0xFF);
+                }
+            }
+        }
+    };
+    // OpenCV fixed-point bilinear of this band from its gray bytes + max over the sampled frames -> ring slot.  The four
+    // pixels of a thread are made two at a time (8 taps in flight, not 16): the other env's 24 piece registers are live here
+    auto resize_store = [&](const unsigned char *gray, int n, int nvalid, int slot, bool clear) {
+        if (tid >= FBR * ow4) return;
+        const int dyl = FastDiv(ow4).div(tid), xq = tid - dyl * ow4;
+        const int dy = dy0 + dyl;
+        uint32_t b0s = 0, b1s = 0;
+        if (nvalid) {
+            const int4 yt = ytab_s[dyl];
+            b0s = (uint32_t)yt.z << 8;
+            b1s = (uint32_t)yt.w << 8;
+        }
+        const unsigned char *row0 = gray + mul_u24((uint32_t)dyl, kRawW * 2);
+        constexpr uint32_t fstride = (uint32_t)FBR * kRawW * 2;
+        const uint32_t keep0 = nvalid > 0 ? 0xFFu : 0u, keep1 = nvalid > 1 ? 0xFFu : 0u;
+        uint32_t packed = 0;
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            int4 xt = make_int4(0, 0, 0, 0);
+            if (nvalid) xt = *reinterpret_cast<const int4 *>(xtab_s + xq * 4 + 2 * h);
+            const int xi[2] = {xt.x, xt.z};
+            const int xa[2] = {xt.y, xt.w};
+            uint32_t pp[2][2][2];
+#pragma unroll
+            for (int k = 0; k < 2; ++k)
+#pragma unroll
+                for (int f = 0; f < 2; ++f) {
+                    const uint16_t *row = reinterpret_cast<const uint16_t *>(row0 + f * fstride);
+                    pp[k][f][0] = row[xi[k] & 0xFFFF];
+                    pp[k][f][1] = row[(uint32_t)xi[k] >> 16];
+                }
+#pragma unroll
+            for (int k = 0; k < 2; ++k) {
+                typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
+                const u16x2 aa = __builtin_bit_cast(u16x2, (uint32_t)xa[k] << 4);
+                uint32_t v[2];
+#pragma unroll
+                for (int f = 0; f < 2; ++f) {
+                    const uint32_t p0 = pp[k][f][0], p1 = pp[k][f][1];
+                    const uint32_t top = __builtin_amdgcn_perm(p1, p0, 0x0C040C00u);
+                    const uint32_t bot = __builtin_amdgcn_perm(p1, p0, 0x0C050C01u);
+                    const uint32_t h0 = __builtin_amdgcn_udot2(__builtin_bit_cast(u16x2, top), aa, 0u, false);
+                    const uint32_t h1 = __builtin_amdgcn_udot2(__builtin_bit_cast(u16x2, bot), aa, 0u, false);
+                    v[f] = (mul_hi_u24(b0s, h0 & 0xFFFFFF00u) + mul_hi_u24(b1s, h1 & 0xFFFFFF00u) + 2) >> 2;
+                }
+                packed |= max(v[0] & keep0, v[1] & keep1) << (8 * (2 * h + k));
+            }
+            if (h == 0) __builtin_amdgcn_sched_barrier(0);
+        }
+        const uint32_t fsz = (uint32_t)p.oh * p.ow;
+        uint8_t *env = p.ring + (size_t)n * p.fs * fsz;
+        const uint32_t off = mad_u24((uint32_t)dy, (uint32_t)p.ow, (uint32_t)xq * 4);
+        *reinterpret_cast<uint32_t *>(env + (slot * fsz + off)) = packed;
+        if (clear)
+            for (int s = 0; s < p.fs - 1; ++s) *reinterpret_cast<uint32_t *>(env + (s * fsz + off)) = 0u;
+    };
+
+    bool skipA, clearA, skipB = true, clearB = false;
+    int nvA, slotA, nvB = 0, slotB = 0;
+    flags(cmdA, headA, n0, skipA, clearA, nvA, slotA);
+    if (two) flags(cmdB, headB, n0 + 1, skipB, clearB, nvB, slotB);
+    if (!skipA && nvA > 0) luminance(fb0, gray0, nvA);
+    // the second env's pieces, into the registers the first env's luminance has just released (the scheduling barriers
+    // keep the compiler from hoisting them above that luminance - which would need a second register set - or sinking
+    // them below the resize they are meant to fly under)
+    __builtin_amdgcn_sched_barrier(0);
+    if (two) {
+#pragma unroll
+        for (int it = 0; it < kIter; ++it) {
+            uint32_t a, b;
+            offsets(it, a, b);
+            w0[it] = load_piece(fb1 + a);
+            w1[it] = load_piece(fb1 + b);
+        }
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    __syncthreads();
+    if (!skipA) resize_store(gray0, n0, nvA, slotA, clearA);
+    if (two && !skipB) {
+        if (nvB > 0) luminance(fb1, gray1, nvB);
+        __syncthreads();
+        resize_store(gray1, n0 + 1, nvB, slotB, clearB);
+    }
+}
+
 // K1g: the same from ALE grayscale screens u8 [N][2][210][160] (agx_ingest_gray_raw)
 __global__ __launch_bounds__(kThreads) void k_ingest_grayraw(IngestParams p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
