@@ -133,6 +133,11 @@ class NativeHostRunner:
         except Exception:  # noqa: BLE001
             pass
 
+    def set_frames(self, frames: np.ndarray):
+        """Point the runner at another staging buffer of the same shape (double-buffered pinned staging)."""
+        assert frames.shape == self.frames.shape and frames.dtype == np.uint8 and frames.flags.c_contiguous
+        self.frames = frames
+
     def train(self):
         self.training = True
         self._lib.agxr_set_training(self._h, 1)

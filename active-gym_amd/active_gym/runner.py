@@ -90,6 +90,11 @@ class AtariHostRunner:
             self._pool.shutdown(wait=True)
             self._pool = None
 
+    def set_frames(self, frames: np.ndarray):
+        """Point the runner at another staging buffer of the same shape (double-buffered pinned staging)."""
+        assert frames.shape == self.frames.shape and frames.dtype == np.uint8 and frames.flags.c_contiguous
+        self.frames = frames
+
     def train(self):
         self.training = True
 

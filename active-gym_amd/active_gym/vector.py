@@ -180,15 +180,24 @@ class AtariVecEnv:
         self._gray = fmt == "gray"
         px = () if self._gray else (3,)
         shape = (self.num_envs, 2, nat.RAW_H, nat.RAW_W) + px
-        self._h_frames = torch.empty(shape, dtype=torch.uint8, pin_memory=True)
+        # Two pinned staging sets (screens, command bytes, copy-done event), used alternately: with device outputs step()
+        # returns without synchronising, so the emulators of step t+1 fill one set while the H2D copy of step t still
+        # drains the other (host-side double buffering; on the device the copies are stream-ordered behind the kernels
+        # that read the previous screens, so one device buffer is enough)
+        nstage = 1 if self._numpy_out else 2
+        self._stage = [{"frames": torch.empty(shape, dtype=torch.uint8, pin_memory=True),
+                        "cmd": torch.empty((self.num_envs,), dtype=torch.uint8, pin_memory=True),
+                        "ev": torch.cuda.Event()} for _ in range(nstage)]
+        self._stage_i = 0
+        self._h_frames = self._stage[0]["frames"]
         self._d_frames = torch.empty(shape, dtype=torch.uint8, device=self.device)
         # reset screens get their own pinned buffer: the autoreset inside step() must not overwrite step
         # screens whose asynchronous H2D copy may still be in flight
         self._h_rframes = torch.empty((self.num_envs, 1, nat.RAW_H, nat.RAW_W) + px, dtype=torch.uint8, pin_memory=True)
         self._h_rcmd = torch.empty((self.num_envs,), dtype=torch.uint8, pin_memory=True)
-        self._ev_copy = torch.cuda.Event()
+        self._ev_copy = self._stage[0]["ev"]
         self._ev_rcopy = torch.cuda.Event()
-        self._h_cmd = torch.empty((self.num_envs,), dtype=torch.uint8, pin_memory=True)
+        self._h_cmd = self._stage[0]["cmd"]
         self._d_cmd = torch.empty((self.num_envs,), dtype=torch.uint8, device=self.device)
         src = getattr(args, "frame_source", "ale")
         if isinstance(src, str) and src.startswith("native"):
@@ -275,6 +284,15 @@ class AtariVecEnv:
     def _out(self, t: torch.Tensor):
         return t.cpu().numpy() if self._numpy_out else t
 
+    def _next_stage(self):
+        st = getattr(self, "_stage", None)
+        if st is not None and len(st) > 1:
+            self._stage_i ^= 1
+            cur = st[self._stage_i]
+            self._h_frames, self._h_cmd, self._ev_copy = cur["frames"], cur["cmd"], cur["ev"]
+            self.runner.set_frames(self._h_frames.numpy())
+        self._ev_copy.synchronize()             # this set's previous screens have left the pinned buffer
+
     def _next_obs_buffer(self):
         self._obs_i = (self._obs_i + 1) % len(self._obs_bufs)
         self._obs = self._obs_bufs[self._obs_i]
@@ -319,6 +337,8 @@ class AtariVecEnv:
     # ------------------------------------------------------------------ API
     def reset(self, seed=None, options=None):
         """Reset every env (the reference ignores seed/options too, atari_env.py:150-152)."""
+        for st in getattr(self, "_stage", []):
+            st["ev"].synchronize()
         self._ev_copy.synchronize()
         self._ev_rcopy.synchronize()
         cmd = self.runner.reset(out=self._h_rframes.numpy())
@@ -346,7 +366,7 @@ class AtariVecEnv:
                 stype = self._as_device_action(action["sensory_action_type"], 0).to(torch.int32)
         if isinstance(motor, torch.Tensor):
             motor = motor.detach().cpu().numpy()
-        self._ev_copy.synchronize()             # the previous step's screens have left the pinned buffer
+        self._next_stage()                      # the other pinned set; waits only for the copy issued from it two steps ago
         self._next_obs_buffer()
         chunk = int(getattr(self.args, "h2d_chunk_envs", 0) or 0)
         if chunk > 0 and hasattr(self.runner, "step_begin"):

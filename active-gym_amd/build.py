@@ -61,12 +61,13 @@ RUNNER_OUT = os.path.join(OUT_DIR, "libagx_runner.so")
 
 
 def build_runner(force=False, verbose=False):
-    """The native host runner (include/agx_runner.h): plain C++17 + pthreads, no GPU code."""
+    """The native host runner (include/agx_runner.h): plain C++17 + pthreads, no GPU code.  -O3 -mavx2: the scripted
+    emulator's screen loops vectorise (2.4x on RGB screens); every MI355X host CPU (EPYC Zen 4/5) has AVX2."""
     deps = [RUNNER_SRC, os.path.join(REPO, "include", "agx_runner.h")]
     if not force and os.path.exists(RUNNER_OUT) and all(os.path.getmtime(RUNNER_OUT) >= os.path.getmtime(d) for d in deps):
         return RUNNER_OUT
     os.makedirs(OUT_DIR, exist_ok=True)
-    cmd = ["g++", "-O2", "-ffp-contract=off", "-std=c++17", "-fPIC", "-shared", "-fvisibility=hidden", "-Wall", "-I", os.path.join(REPO, "include"),
+    cmd = ["g++", "-O3", "-mavx2", "-ffp-contract=off", "-std=c++17", "-fPIC", "-shared", "-fvisibility=hidden", "-Wall", "-I", os.path.join(REPO, "include"),
            RUNNER_SRC, "-o", RUNNER_OUT + ".tmp", "-pthread", "-ldl"]
     if verbose:
         print(" ".join(cmd))

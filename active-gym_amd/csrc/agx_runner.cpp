@@ -102,9 +102,13 @@ struct ScriptedEmu final : Emulator {
             }
             lut[v8] = (uint8_t)q;
         }
-        for (int y = 0; y < kH; ++y)
+        for (int y = 0; y < kH; ++y) {
+            uint8_t idx[kW];                                   // the index arithmetic vectorises; the table walk follows
             for (int x = 0; x < kW; ++x)
-                out[(size_t)y * kW + x] = lut[((uint32_t)(y * 7 + x * 13) + K * 3u + (uint32_t)((y * x) >> 4)) & 0xFF];
+                idx[x] = (uint8_t)((uint32_t)(y * 7 + x * 13) + K * 3u + (uint32_t)((y * x) >> 4));
+            uint8_t *row = out + (size_t)y * kW;
+            for (int x = 0; x < kW; ++x) row[x] = lut[idx[x]];
+        }
     }
     std::vector<int> minimal_actions() override {
         std::vector<int> v(n_actions);

@@ -240,14 +240,15 @@ def cpu_baseline(budget_s, seed):
 
 def run_e2e(dev, n, hc):
     """PCIe- and emulator-inclusive rate through the drop-in API (never `value`): AtariVecEnv.step = native C++ host
-    runner (scripted emulator, one thread per core) -> pinned staging -> chunked hipMemcpyAsync -> ingest + fovea ->
-    device observations; RGB screens (the metric's input format, north_star) and ALE grayscale screens (what the
+    runner (scripted emulator, one thread per core) -> pinned staging (two sets, alternating) -> hipMemcpyAsync ->
+    ingest + fovea -> device observations; RGB screens (the metric's input format, north_star) and ALE grayscale screens (what the
     reference reads, atari_env.py:74).  Bounded: a few dozen steps each."""
     import numpy as np
     import torch
     from active_gym import AtariEnvArgs, AtariVecEnv
     workers = max(1, min(64, hc["present"]))      # emulator threads (mostly memory-bound screen writes); the job's CPU quota is hc["usable"]
-    out = {"envs": n, "runner": "libagx_runner.so (C++ threads, scripted emulator)", "workers": workers, "h2d_chunk_envs": 128,
+    out = {"envs": n, "runner": "libagx_runner.so (C++ threads, scripted emulator)", "workers": workers, "h2d_chunk_envs": 0,
+           "overlap": "double-buffered pinned staging: the emulators of step t+1 run under the H2D copy and kernels of step t",
            "host_cores_usable": hc["usable"], "host_cores_present": hc["present"]}
     h = torch.empty((n, 2, 210, 160, 3), dtype=torch.uint8).pin_memory()
     d = torch.empty_like(h, device=dev)
@@ -264,7 +265,7 @@ def run_e2e(dev, n, hc):
     for fmt, steps in (("rgb", 12), ("gray", 24)):
         args = AtariEnvArgs(frame_format=fmt, game="breakout", seed=1, obs_size=(84, 84), fov_size=(30, 30), fov_init_loc=(0, 0),
                             sensory_action_mode="absolute", resize_to_full=True, frame_source="native", device=str(dev),
-                            num_workers=workers, h2d_chunk_envs=128)
+                            num_workers=workers, h2d_chunk_envs=0)
         env = AtariVecEnv(args, n, kind="fixed")
         env.reset()
         env.step(act)
