@@ -72,6 +72,7 @@ struct agx_ctx {
         int flex_v2 = 0;         // AGX_FLEX_V2           K4 resize_to_full through k_fovea_flexible2 (pass-by-pass form)
         int per_v2 = 0;          // AGX_PER_V2            K3 through k_fovea_peripheral2
         int pair12 = 0;          // AGX_INGEST_PAIR12     k_ingest_pair12: two envs' bands per workgroup, second env's loads under the first's tail
+        int step_env = 0;        // AGX_STEP_ENV          agx_step_fixed as ONE launch, one workgroup per env (k_step_env)
         int split = 0;           // AGX_STEP_SPLIT        env-range parts of agx_step_fixed on internal streams (default 1 = one launch pair)
         int aux_prio = 0;        // AGX_STEP_AUX_PRIO     -1 | 0 | 1: priority of the internal streams relative to normal
     } tune;
@@ -407,6 +408,7 @@ int agx_create(const agx_config *cfg, agx_ctx **out) {
     ctx->tune.flex_v2 = env_int("AGX_FLEX_V2");
     ctx->tune.per_v2 = env_int("AGX_PER_V2");
     ctx->tune.pair12 = env_int("AGX_INGEST_PAIR12");
+    ctx->tune.step_env = env_int("AGX_STEP_ENV");
     ctx->tune.split = env_int("AGX_STEP_SPLIT");
     ctx->tune.aux_prio = env_int("AGX_STEP_AUX_PRIO", 0);
     DeviceGuard g(c.device);
@@ -962,6 +964,28 @@ int agx_step_fixed(agx_ctx *ctx, const uint8_t *d_frames, const uint8_t *d_cmd, 
     // than the overlap returns (round 1's +6-10 % came from two independent contexts that never join).  So it is opt-in.
     int parts = tn.split > 0 ? tn.split : 1;
     parts = std::min(std::min(parts, 4), c.num_envs);
+    // ---- one launch, one workgroup per env (agx_step_env.h): the headline geometry's resize_to_full path
+    if (tn.step_env != 0 && default_forms && !mid_event && c.out_mode == AGX_OUT_RESIZE && c.obs_h == 84 && c.obs_w == 84 &&
+        c.fov_h == 30 && c.fov_w == 30 && ctx->y_affine && ctx->band_rows == 12 && c.frame_stack >= 1) {
+        DeviceGuard g(c.device);
+        const IngestParams pi = ingest_params(ctx, d_frames, d_cmd);
+        FovParams pf = fov_params(ctx, d_action, action_dtype, nullptr, nullptr, d_obs, d_fov_loc, nullptr);
+        pf.cmd = d_cmd;
+        pf.phase = 3;                                        // `head` is the pre-ingest head, every slot is processed
+        pf.head = ctx->head[ctx->cur_head];
+        const size_t team_lds = (std::max(ingest_lds(ctx), fixed_lds(c)) + 15) & ~(size_t)15;
+        using GS = GeomS<84, 84, 30, 30>;
+        StepEnvArgs sa;
+        sa.pi = pi;
+        sa.pf = pf;
+        sa.team_lds = (int32_t)team_lds;
+        sa.debug = env_int("AGX_STEP_ENV_DEBUG", 0);
+        hipLaunchKernelGGL((k_step_env<GS>), dim3(c.num_envs), dim3(2 * kThreads), 2 * team_lds, S(stream), sa);
+        AGX_HIP(ctx, hipGetLastError());
+        ctx->cur_head ^= 1;
+        ctx->cur_fov ^= 1;
+        return AGX_OK;
+    }
     if (parts > 1 && default_forms && c.obs_h == c.obs_w && !mid_event) {
         DeviceGuard g(c.device);
         if (!ctx->ev_fork) {

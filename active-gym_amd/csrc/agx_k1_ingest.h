@@ -122,8 +122,8 @@ struct IngestParams {
 // row form: the row job of iteration `it` is (frame it / 2, row rg + RG * (it % 2)) with no clamping against a ragged
 // last band, so the second frame's offsets are the first's plus a constant and the index arithmetic folds away.
 template <int T, bool GRAY = false, int FBR = 0>
-__device__ __forceinline__ void ingest_band(const IngestParams &p, const int band, const int n, unsigned char *smem) {
-    const int tid = threadIdx.x;
+__device__ __forceinline__ void ingest_band(const IngestParams &p, const int band, const int n, unsigned char *smem,
+                                            const int tid) {
     AGX_STAMP(0);
     constexpr uint32_t kRowB = GRAY ? kRawW : kRawRowBytes;               // source row / frame pitch in bytes
     constexpr uint32_t kFrameB = kRawH * kRowB;
@@ -322,6 +322,10 @@ __device__ __forceinline__ void ingest_band(const IngestParams &p, const int ban
             for (int s = 0; s < p.fs - 1; ++s) *reinterpret_cast<uint32_t *>(env + (s * fsz + off)) = 0u;
     }
     AGX_STAMP(4);
+}
+template <int T, bool GRAY = false, int FBR = 0>
+__device__ __forceinline__ void ingest_band(const IngestParams &p, const int band, const int n, unsigned char *smem) {
+    ingest_band<T, GRAY, FBR>(p, band, n, smem, (int)threadIdx.x);
 }
 
 template <int T>

@@ -35,10 +35,11 @@ __device__ __forceinline__ void store_obs(T4 *dst, const T4 &v) {
 //           lane, lane-linear, 1 KiB per wave at 1-KiB steps, nontemporal.
 // (ablation of the previous serial version at N=1024: loc chain 5.8 us, loc-dependent window load
 //  6.3 us, H pass with a tap load per iteration 7.3 us, row-tap loads 2.1 us of a 32.7 us launch.)
-template <class G, int MODE>
+// COHERENT: the frame is read with agent-scope loads (global_load_dword sc1: served by L2, never by this CU's L1) - for a
+// slot that the same launch has just written (k_step_env); phase 3: `head` is the pre-ingest head, every slot is processed.
+template <class G, int MODE, bool COHERENT = false>
 __device__ __forceinline__ void fovea_fixed_body(const G g, const FovParams &p, const int sl, const int n,
-                                                 unsigned char *smem) {
-    const int tid = threadIdx.x;
+                                                 unsigned char *smem, const int tid) {
     constexpr int T = kThreads;
     (void)T;
     AGX_STAMP(0);
@@ -54,14 +55,14 @@ __device__ __forceinline__ void fovea_fixed_body(const G g, const FovParams &p, 
         const int h = uniform_load_i32(p.head + n);
         // slot the ingest writes: the pre-ingest head (fs-1 after a clear, which also zeroes the others)
         int wslot;
-        if (p.phase == 1) {
+        if (p.phase == 1 || p.phase == 3) {
             wslot = h;
             head_fixup = skip ? 0 : (clear ? -h : (h + 1 == p.fs ? 1 - p.fs : 1));
         } else {
             wslot = skip ? h : (h == 0 ? p.fs - 1 : h - 1);
         }
         const bool touched = clear || sl == wslot;
-        if ((p.phase == 1) == touched) return;            // phase 1 takes the untouched slots, phase 2 the rest
+        if (p.phase != 3 && (p.phase == 1) == touched) return;   // phase 1 takes the untouched slots, phase 2 the rest
     }
     // LDS carve: lut[256] | raw[oh*ow] u8 | ytab[oh] | H[fh][ow]
     float *lut = reinterpret_cast<float *>(smem);
@@ -79,7 +80,10 @@ __device__ __forceinline__ void fovea_fixed_body(const G g, const FovParams &p, 
     constexpr int kFW = 7;                                            // 7 * 256 dwords cover 84x84; loop beyond
     uint32_t fw_[kFW];
 #pragma unroll
-    for (int k = 0; k < kFW; ++k) fw_[k] = fsrc[min(tid + k * kThreads, fwords - 1)];
+    for (int k = 0; k < kFW; ++k) {
+        const uint32_t *q = fsrc + min(tid + k * kThreads, fwords - 1);
+        fw_[k] = COHERENT ? __hip_atomic_load(q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : *q;
+    }
     const int xcol = tid % ow, yb = tid / ow;                         // phase-C column / first row
     int4 xt = make_int4(0, 0, 0, 0), yt = xt;                         // raw Tap bits {lo, aux, a, b}
     if (MODE == AGX_OUT_RESIZE) {
@@ -111,7 +115,8 @@ __device__ __forceinline__ void fovea_fixed_body(const G g, const FovParams &p, 
 #pragma unroll
     for (int k = 0; k < kFW; ++k)
         if (tid + k * kThreads < fwords) reinterpret_cast<uint32_t *>(raw)[tid + k * kThreads] = fw_[k];
-    for (int i = tid + kFW * kThreads; i < fwords; i += kThreads) reinterpret_cast<uint32_t *>(raw)[i] = fsrc[i];
+    for (int i = tid + kFW * kThreads; i < fwords; i += kThreads)
+        reinterpret_cast<uint32_t *>(raw)[i] = COHERENT ? __hip_atomic_load(fsrc + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : fsrc[i];
     if (MODE == AGX_OUT_RESIZE) {
         if (tid < oh) *reinterpret_cast<int4 *>(ytab_s + tid) = yt;
         for (int i = tid + kThreads; i < oh; i += kThreads) ytab_s[i] = p.ytab[i];
@@ -153,13 +158,13 @@ __device__ __forceinline__ void fovea_fixed_body(const G g, const FovParams &p, 
             const float wa = __int_as_float(xt.z), wb = __int_as_float(xt.w);
 #pragma unroll 10
             for (int y = yb; y < fh; y += rstep)
-                H[y * ow + xcol] = wa * lut[c0[y * ow]] + wb * lut[c1[y * ow]];
+                H[y * ow + xcol] = fmaf(wb, lut[c1[y * ow]], wa * lut[c0[y * ow]]);
         }
     } else {                                                          // ow > 256: generic striding
         for (int i = tid; i < fh * ow; i += kThreads) {
             const int y = i / ow, x = i - y * ow;
             const Tap t = p.xtab[x];
-            H[i] = t.a * lut[win[y * ow + t.lo]] + t.b * lut[win[y * ow + t.aux]];
+            H[i] = fmaf(t.b, lut[win[y * ow + t.aux]], t.a * lut[win[y * ow + t.lo]]);
         }
     }
     __syncthreads();
@@ -172,14 +177,22 @@ __device__ __forceinline__ void fovea_fixed_body(const G g, const FovParams &p, 
         const Tap t = ytab_s[row];
         const float4 a = H4[t.lo * ow4 + x4];
         const float4 b = H4[t.aux * ow4 + x4];
+        // the lerp is written as mul + fma explicitly: every instantiation of this body (stand-alone, pair, fused, per-env
+        // step) then rounds the same way whatever contraction the optimiser would pick in its context
         float4 o;
-        o.x = t.a * a.x + t.b * b.x;
-        o.y = t.a * a.y + t.b * b.y;
-        o.z = t.a * a.z + t.b * b.z;
-        o.w = t.a * a.w + t.b * b.w;
+        o.x = fmaf(t.b, b.x, t.a * a.x);
+        o.y = fmaf(t.b, b.y, t.a * a.y);
+        o.z = fmaf(t.b, b.z, t.a * a.z);
+        o.w = fmaf(t.b, b.w, t.a * a.w);
         store_obs(&out4[q], o);
     }
     AGX_STAMP(4);
+}
+
+template <class G, int MODE>
+__device__ __forceinline__ void fovea_fixed_body(const G g, const FovParams &p, const int sl, const int n,
+                                                 unsigned char *smem) {
+    fovea_fixed_body<G, MODE, false>(g, p, sl, n, smem, (int)threadIdx.x);
 }
 
 template <class G, int MODE>
@@ -264,13 +277,13 @@ __global__ __launch_bounds__(kThreads) void k_fovea_fixed2(G g, FovParams p) {
             if (yb < rstep) {
                 const unsigned char *c0 = win + xt.x, *c1 = win + xt.y;
 #pragma unroll 10
-                for (int y = yb; y < fh; y += rstep) H[y * ow + xcol] = wa * lut[c0[y * ow]] + wb * lut[c1[y * ow]];
+                for (int y = yb; y < fh; y += rstep) H[y * ow + xcol] = fmaf(wb, lut[c1[y * ow]], wa * lut[c0[y * ow]]);
             }
         } else {
             for (int i = tid; i < fh * ow; i += kThreads) {
                 const int y = i / ow, x = i - y * ow;
                 const Tap t = p.xtab[x];
-                H[i] = t.a * lut[win[y * ow + t.lo]] + t.b * lut[win[y * ow + t.aux]];
+                H[i] = fmaf(t.b, lut[win[y * ow + t.aux]], t.a * lut[win[y * ow + t.lo]]);
             }
         }
         __syncthreads();
@@ -284,10 +297,10 @@ __global__ __launch_bounds__(kThreads) void k_fovea_fixed2(G g, FovParams p) {
             const float4 a = H4[t.lo * ow4 + x4];
             const float4 b = H4[t.aux * ow4 + x4];
             float4 o;
-            o.x = t.a * a.x + t.b * b.x;
-            o.y = t.a * a.y + t.b * b.y;
-            o.z = t.a * a.z + t.b * b.z;
-            o.w = t.a * a.w + t.b * b.w;
+            o.x = fmaf(t.b, b.x, t.a * a.x);
+            o.y = fmaf(t.b, b.y, t.a * a.y);
+            o.z = fmaf(t.b, b.z, t.a * a.z);
+            o.w = fmaf(t.b, b.w, t.a * a.w);
             store_obs(&out4[q], o);
         }
     }

@@ -401,7 +401,7 @@ def main():
     fused = args.kind == "fixed" and args.fused and os.environ.get("AGX_STEP_FUSED") is not None
     # --split: agx_step_fixed's split step; the sampled steps (every M-th) still run as two stand-alone full-batch
     # launches carrying their own HIP events - the per-kernel roofline is a solo figure
-    split = args.kind == "fixed" and not gray and not fused and args.split
+    split = args.kind == "fixed" and not gray and not fused and (args.split or os.environ.get("AGX_STEP_ENV"))
 
     kernel_events = args.event_mode == "kernel" and not fused
 

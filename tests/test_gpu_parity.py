@@ -585,13 +585,13 @@ def test_ingest_gray_raw_matches_oracle_and_rgb_path(dev, obs):
 
 # ---------------------------------------------------------------- every tuning variant == the default, bit for bit
 _KNOBS = ("AGX_INGEST_NO_FULL", "AGX_INGEST_T", "AGX_INGEST_BAND_ROWS", "AGX_INGEST_PIPE", "AGX_INGEST_WAVE", "AGX_FOVEA_PAIR", "AGX_STEP_FUSED",
-          "AGX_FOVEA_GENERIC", "AGX_PER_V2", "AGX_FLEX_V2", "AGX_STEP_SPLIT", "AGX_STEP_AUX_PRIO", "AGX_INGEST_PAIR12")
+          "AGX_FOVEA_GENERIC", "AGX_PER_V2", "AGX_FLEX_V2", "AGX_STEP_SPLIT", "AGX_STEP_AUX_PRIO", "AGX_INGEST_PAIR12", "AGX_STEP_ENV")
 
 
 @pytest.mark.parametrize("knob", [{"AGX_INGEST_T": "128"}, {"AGX_INGEST_BAND_ROWS": "7"}, {"AGX_INGEST_BAND_ROWS": "11"},
                                   {"AGX_INGEST_PIPE": "2"}, {"AGX_INGEST_PIPE": "7"}, {"AGX_INGEST_WAVE": "1"}, {"AGX_INGEST_NO_FULL": "1"},
                                   {"AGX_INGEST_PAIR12": "1"},
-                                  {"AGX_FOVEA_PAIR": "1"}, {"AGX_STEP_FUSED": "1"}, {"AGX_STEP_SPLIT": "2"}, {"AGX_STEP_SPLIT": "3"},
+                                  {"AGX_FOVEA_PAIR": "1"}, {"AGX_STEP_FUSED": "1"}, {"AGX_STEP_SPLIT": "2"}, {"AGX_STEP_SPLIT": "3"}, {"AGX_STEP_ENV": "1"},
                                   {"AGX_STEP_SPLIT": "4", "AGX_STEP_AUX_PRIO": "-1"},
                                   {"AGX_INGEST_T": "128", "AGX_FOVEA_PAIR": "1"}], ids=lambda k: ",".join(f"{a}={b}" for a, b in k.items()))
 def test_kernel_variants_bit_identical(dev, knob, monkeypatch):
@@ -620,7 +620,7 @@ def test_kernel_variants_bit_identical(dev, knob, monkeypatch):
         act = _t(rng.uniform(-5, 60, (N, 2)).astype(np.float32), dev)
         d.ingest(frames, cmd)
         od, ld = d.fovea(act)
-        if "AGX_STEP_FUSED" in knob or "AGX_STEP_SPLIT" in knob:
+        if "AGX_STEP_FUSED" in knob or "AGX_STEP_SPLIT" in knob or "AGX_STEP_ENV" in knob:
             ov, lv = v_.step_fixed(frames, cmd, act)
         else:
             v_.ingest(frames, cmd)
