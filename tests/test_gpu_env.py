@@ -433,3 +433,24 @@ def test_readme_quickstart_action_space_sample_steps(factory, mode):
         want[done] = (10, 20)                                                   # autoreset re-initialises fov_loc (fov_env.py:156-160)
         assert np.array_equal(info["fov_loc"], want)
         venv.close()
+
+
+@pytest.mark.skipif(torch.cuda.device_count() < 2, reason="needs two visible GPUs")
+def test_vec_env_on_a_device_that_is_not_the_current_one():
+    """copy-done events must be recorded on the pipeline's stream, not on the current device's current
+    stream.  With kind='base' and device outputs nothing else synchronises the pinned staging buffer."""
+    from active_gym import AtariEnvArgs, AtariVecEnv
+    torch.cuda.set_device(0)
+    args = AtariEnvArgs(game="boxing", seed=0, obs_size=(84, 84), frame_source="native", device="cuda:1")
+    ref_args = AtariEnvArgs(game="boxing", seed=0, obs_size=(84, 84), frame_source="native", device="cuda:0")
+    a, b = AtariVecEnv(args, 8, kind="base", noop_per_env=True), AtariVecEnv(ref_args, 8, kind="base", noop_per_env=True)
+    oa, _ = a.reset()
+    ob, _ = b.reset()
+    assert oa.device.index == 1 and torch.equal(oa.cpu(), ob.cpu())
+    for _ in range(20):
+        m = np.random.randint(0, 4, 8)
+        oa = a.step(m)[0]
+        ob = b.step(m)[0]
+        assert torch.equal(oa.cpu(), ob.cpu())
+    a.close()
+    b.close()
