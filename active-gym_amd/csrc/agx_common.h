@@ -40,6 +40,16 @@ __device__ __forceinline__ float unit(uint32_t k) { return (float)k / 255.0f; }
 
 
 
+// float32(k) / 255 correctly rounded without the division sequence: q = k * y, r = k - 255 q (exact in an FMA),
+// q + r * y with y = RN(1/255) (Markstein).  tests/host_tables_harness.cpp and the GPU parity tests check all 256
+// values bit for bit against the IEEE quotient.
+__host__ __device__ __forceinline__ float unit_fast(float k) {
+    const float y = 1.0f / 255.0f;
+    const float q = k * y;
+    const float r = fmaf(-q, 255.0f, k);
+    return fmaf(r, y, q);
+}
+
 // Wave-uniform byte through the scalar cache.  hipcc emits a VECTOR load + s_waitcnt vmcnt(0) for
 // `p.cmd[n]` (it cannot prove the buffer read-only), i.e. a full memory round trip in front of the
 // first frame load of every workgroup; s_load_dword is counted on lgkmcnt and served by the scalar

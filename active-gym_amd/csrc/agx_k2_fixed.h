@@ -158,7 +158,9 @@ __device__ __forceinline__ void fovea_fixed_body(const G g, const FovParams &p, 
             const float wa = __int_as_float(xt.z), wb = __int_as_float(xt.w);
 #pragma unroll 10
             for (int y = yb; y < fh; y += rstep)
-                H[y * ow + xcol] = fmaf(wb, lut[c1[y * ow]], wa * lut[c0[y * ow]]);
+                // u8 -> float32 k/255 by unit_fast (3 FMAs, the correctly rounded quotient) rather than through the LDS table:
+                // one LDS round trip less in the chain byte -> value -> lerp (23.0-23.4 vs 23.2-23.8 us, a tie at worst)
+                H[y * ow + xcol] = fmaf(wb, unit_fast((float)c1[y * ow]), wa * unit_fast((float)c0[y * ow]));
         }
     } else {                                                          // ow > 256: generic striding
         for (int i = tid; i < fh * ow; i += kThreads) {

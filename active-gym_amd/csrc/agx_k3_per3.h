@@ -44,16 +44,6 @@ struct Per3Params {
     int32_t same;         // peripheral_res == obs_size: torchvision returns the input unchanged
 };
 
-// float32(k) / 255 correctly rounded without the division sequence: q = k * y, r = k - 255 q (exact in an FMA),
-// q + r * y with y = RN(1/255) (Markstein).  tests/host_tables_harness.cpp and the GPU parity tests check all 256
-// values bit for bit against the IEEE quotient.
-__host__ __device__ __forceinline__ float unit_fast(float k) {
-    const float y = 1.0f / 255.0f;
-    const float q = k * y;
-    const float r = fmaf(-q, 255.0f, k);
-    return fmaf(r, y, q);
-}
-
 template <class G, int MT>
 __global__ __launch_bounds__(kThreads) void k_fovea_peripheral3(G g, Per3Params t, FovParams p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
