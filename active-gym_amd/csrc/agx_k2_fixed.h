@@ -26,7 +26,8 @@ __device__ __forceinline__ void store_obs(T4 *dst, const T4 &v) {
 
 // grid = (fs, N): workgroup (sl, n) owns PHYSICAL ring slot sl of env n, block = 256.
 // Every stage that costs a memory round trip is started at once:
-//   * the whole u8 frame of that slot (address known at launch) -> registers -> LDS,
+//   * the u8 frame of that slot -> registers -> LDS (resize_to_full: only its fh window rows, requested as soon as the
+//     env's state has given the window's first row; mask-out / raw crop: the whole frame, address known at launch),
 //   * the scalar chain action / fov_loc / head -> (r, c) and the stack position j of this slot,
 //   * this thread's column taps (registers) and one row-tap entry (-> LDS).
 // u8 -> float32 k/255 goes through a 256-entry LDS table (one exact division per thread).
@@ -75,7 +76,59 @@ __device__ __forceinline__ void fovea_fixed_body(const G g, const FovParams &p, 
     // ---- every round trip starts now: the frame, the taps, then the small state loads.  (The first
     // use of the state waits for everything older too, which is fine: all of it is needed before the
     // LDS image can be written; what matters is that nothing waits before everything is issued.)
+    // RESIZE: only the fh window rows of the slot are fetched, after the state (see below); -DAGX_K2_FULL_FRAME restores the
+    // whole-frame prologue of round 1 (same box, N = 1024: K2 23.0-23.2 -> 21.7-22.1 us, step 60.7 -> 59.4 us)
+#if defined(AGX_K2_FULL_FRAME)
+    constexpr bool kWindowOnly = false;
+#else
+    constexpr bool kWindowOnly = MODE == AGX_OUT_RESIZE;
+#endif
     const uint32_t *fsrc = reinterpret_cast<const uint32_t *>(p.ring + ((size_t)n * p.fs + sl) * (size_t)fbytes);
+    int r, c, j;
+    int4 xt = make_int4(0, 0, 0, 0);                                  // this thread's column taps {lo, aux, a, b}
+    if (kWindowOnly) {
+        // State first (vmcnt retires in order), then only the fh window rows of the slot (2.5 KB of the 7 KB frame): every
+        // resident workgroup of the launch starts with this burst, and a third of the bytes returns sooner than the extra
+        // dependent round trip costs (round 1 fetched the whole frame to avoid that dependency: 3.6 us of a wave's 6.7 us
+        // life were the load chain)
+        const LocIn lin = load_loc_inputs(p, n);
+        const int head = p.head[n] + head_fixup;
+        xt = *reinterpret_cast<const int4 *>(p.xtab + tid % ow);
+        const int4 yt0 = *reinterpret_cast<const int4 *>(p.ytab + min(tid, oh - 1));
+        compute_loc(p, lin, oh - fh, ow - fw, r, c);
+        r = __builtin_amdgcn_readfirstlane(r);
+        c = __builtin_amdgcn_readfirstlane(c);
+        j = sl - __builtin_amdgcn_readfirstlane(head);
+        if (j < 0) j += p.fs;
+        const uint32_t *wsrc = fsrc + r * (ow >> 2);
+        const int wwords = (fh * ow) >> 2;
+        constexpr int kW = 3;
+        uint32_t ww[kW];
+#pragma unroll
+        for (int k = 0; k < kW; ++k) {
+            const uint32_t *q = wsrc + min(tid + k * kThreads, wwords - 1);
+            ww[k] = COHERENT ? __hip_atomic_load(q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : *q;
+        }
+        if (sl == 0 && tid == 0) {
+            p.loc_out[2 * n] = r;
+            p.loc_out[2 * n + 1] = c;
+            if (p.user_loc) {
+                p.user_loc[2 * n] = r;
+                p.user_loc[2 * n + 1] = c;
+            }
+        }
+        if (tid < oh) *reinterpret_cast<int4 *>(ytab_s + tid) = yt0;
+        for (int i = tid + kThreads; i < oh; i += kThreads) ytab_s[i] = p.ytab[i];
+#pragma unroll
+        for (int k = 0; k < kW; ++k)
+            if (tid + k * kThreads < wwords) reinterpret_cast<uint32_t *>(raw)[tid + k * kThreads] = ww[k];
+        for (int i = tid + kW * kThreads; i < wwords; i += kThreads)
+            reinterpret_cast<uint32_t *>(raw)[i] = COHERENT ? __hip_atomic_load(wsrc + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : wsrc[i];
+        __syncthreads();
+        r = 0;                                                        // the LDS image starts at the window's first row
+    }
+    const int xcol = tid % ow, yb = tid / ow;                         // phase-C column / first row
+    if (!kWindowOnly) {
     const int fwords = fbytes >> 2;
     constexpr int kFW = 7;                                            // 7 * 256 dwords cover 84x84; loop beyond
     uint32_t fw_[kFW];
@@ -84,8 +137,7 @@ __device__ __forceinline__ void fovea_fixed_body(const G g, const FovParams &p, 
         const uint32_t *q = fsrc + min(tid + k * kThreads, fwords - 1);
         fw_[k] = COHERENT ? __hip_atomic_load(q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : *q;
     }
-    const int xcol = tid % ow, yb = tid / ow;                         // phase-C column / first row
-    int4 xt = make_int4(0, 0, 0, 0), yt = xt;                         // raw Tap bits {lo, aux, a, b}
+    int4 yt = make_int4(0, 0, 0, 0);                                  // raw Tap bits {lo, aux, a, b}
     if (MODE == AGX_OUT_RESIZE) {
         xt = *reinterpret_cast<const int4 *>(p.xtab + xcol);
         yt = *reinterpret_cast<const int4 *>(p.ytab + min(tid, oh - 1));
@@ -93,15 +145,14 @@ __device__ __forceinline__ void fovea_fixed_body(const G g, const FovParams &p, 
     const LocIn lin = load_loc_inputs(p, n);
     const int head = p.head[n] + head_fixup;
     lut[tid] = unit((uint32_t)tid);
-    int r, c;
     compute_loc(p, lin, oh - fh, ow - fw, r, c);
 #ifndef AGX_K2_VECTOR_STATE
     // workgroup-uniform: scalar registers from here on (window base, output base)
     r = __builtin_amdgcn_readfirstlane(r);
     c = __builtin_amdgcn_readfirstlane(c);
-    int j = sl - __builtin_amdgcn_readfirstlane(head);                // stack position of this slot
+    j = sl - __builtin_amdgcn_readfirstlane(head);                    // stack position of this slot
 #else
-    int j = sl - head;
+    j = sl - head;
 #endif
     if (j < 0) j += p.fs;
     if (sl == 0 && tid == 0) {
@@ -125,6 +176,7 @@ __device__ __forceinline__ void fovea_fixed_body(const G g, const FovParams &p, 
     __syncthreads();
     AGX_STAMP(2);
 
+    }
     const unsigned char *win = raw + r * ow + c;                      // window origin inside the frame
     if (MODE == AGX_OUT_RAW) {
         float *out = p.obs + ((size_t)n * p.fs + j) * (size_t)(fh * fw);
