@@ -17,7 +17,7 @@
 //   Hdwn : thread = (output row yf = tid / 8, column phase tid % 8), its row's taps in registers
 //   W    : thread = output column tid % ow (its taps in registers), rows tid / ow + k * (256 / ow)
 //   final: thread = float4 q = tid + 256 k of the frame, row taps from a small LDS table; 16-B nontemporal stores
-// The tables a thread needs are requested as soon as the env's state has arrived, under the frame load.
+// The tables a thread needs and the window's rows of the slot are requested as soon as the env's state has arrived.
 // LDS: R0 = raw frame (+ slack rows read with zero weights) aliased by E on the squeeze path | R1 = D, or E on the
 // plain path | row taps: 21.5 KB for 84x84 / 30x30 -> 7 workgroups per CU.
 #pragma once
@@ -85,7 +85,7 @@ __global__ __launch_bounds__(kThreads) void k_fovea_flexible3(G g, Flex3Params t
         }
         return;
     }
-    const int fbytes = oh * ow, fwords = fbytes >> 2;
+    const int fbytes = oh * ow;
     unsigned char *raw = smem;
     float *R0 = reinterpret_cast<float *>(smem);
     float *R1 = reinterpret_cast<float *>(smem + t.r0_bytes);
@@ -96,12 +96,7 @@ __global__ __launch_bounds__(kThreads) void k_fovea_flexible3(G g, Flex3Params t
     const int2 res_old = *reinterpret_cast<const int2 *>(p.res_in + 2 * n);
     const int type = (p.action && p.action_type) ? p.action_type[n] : AGX_FOV_LOC;
     const int head = p.head[n];
-    // ---- ... then the whole u8 frame of this slot
     const uint32_t *fsrc = reinterpret_cast<const uint32_t *>(p.ring + ((size_t)n * p.fs + sl) * (size_t)fbytes);
-    constexpr int kFW = 7;
-    uint32_t fw_[kFW];
-#pragma unroll
-    for (int k = 0; k < kFW; ++k) fw_[k] = fsrc[min(tid + k * kThreads, fwords - 1)];
 
     // ---- state update (fov_env.py:300-324); res from agx_set_fov_state is clamped for memory safety only
     int rh = min(max(res_old.x, 1), oh), rw = min(max(res_old.y, 1), ow), r, c;
@@ -135,6 +130,17 @@ __global__ __launch_bounds__(kThreads) void k_fovea_flexible3(G g, Flex3Params t
         }
     }
     const bool squeeze = rh > fh;                                     // rows only, fov_env.py:286
+    // ---- ... then the rows of this slot the window needs: [r, r + rh + 8) clipped to the frame (the 8 rows of slack are read
+    // with zero weights; what lies past the frame's end stays whatever the LDS held - bytes, hence finite as floats).  On
+    // average half of the 7 KB frame: the burst every resident workgroup starts with is halved.
+    const int wrows = min(rh + 8, oh - r);
+    const int wwords = (wrows * ow) >> 2;
+    const uint32_t *wsrc = fsrc + r * (ow >> 2);
+    constexpr int kFW = 7;
+    uint32_t fw_[kFW];
+#pragma unroll
+    for (int k = 0; k < kFW; ++k)
+        if (k * kThreads < wwords) fw_[k] = wsrc[min(tid + k * kThreads, wwords - 1)];
 
     // ---- the taps this thread will use, requested now (L2 hits; they land under the frame load)
     const int rstep = kThreads / ow;                                  // rows per sweep of the W passes (3 for ow = 84)
@@ -177,16 +183,16 @@ __global__ __launch_bounds__(kThreads) void k_fovea_flexible3(G g, Flex3Params t
     } else {
         xt = *reinterpret_cast<const int4 *>(t.wf + rw * ow + xcol);
     }
-    // ---- LDS image: the frame, the row taps
+    // ---- LDS image: the window rows (row r of the frame is row 0 of the image), the row taps
 #pragma unroll
     for (int k = 0; k < kFW; ++k)
-        if (tid + k * kThreads < fwords) reinterpret_cast<uint32_t *>(raw)[tid + k * kThreads] = fw_[k];
-    for (int i = tid + kFW * kThreads; i < fwords; i += kThreads) reinterpret_cast<uint32_t *>(raw)[i] = fsrc[i];
+        if (tid + k * kThreads < wwords) reinterpret_cast<uint32_t *>(raw)[tid + k * kThreads] = fw_[k];
+    for (int i = tid + kFW * kThreads; i < wwords; i += kThreads) reinterpret_cast<uint32_t *>(raw)[i] = wsrc[i];
     if (tid < oh) ytab_s[tid] = yt;
     for (int i = tid + kThreads; i < oh; i += kThreads) ytab_s[i] = t.hy[rh * oh + i];
     __syncthreads();
 
-    const unsigned char *win = raw + r * ow + c;                      // window origin inside the frame
+    const unsigned char *win = raw + c;                               // window origin inside the LDS image
     const float *E;
     if (squeeze) {
         // ---- D = Hdwn . crop   (columns up to max(rw, Tw) so that every D element the W pass reads is finite)
