@@ -81,7 +81,7 @@ __device__ __forceinline__ void fovea_fixed_body(const G g, const FovParams &p, 
 #if defined(AGX_K2_FULL_FRAME)
     constexpr bool kWindowOnly = false;
 #else
-    constexpr bool kWindowOnly = MODE == AGX_OUT_RESIZE;
+    constexpr bool kWindowOnly = true;
 #endif
     const uint32_t *fsrc = reinterpret_cast<const uint32_t *>(p.ring + ((size_t)n * p.fs + sl) * (size_t)fbytes);
     int r, c, j;
@@ -93,8 +93,11 @@ __device__ __forceinline__ void fovea_fixed_body(const G g, const FovParams &p, 
         // life were the load chain)
         const LocIn lin = load_loc_inputs(p, n);
         const int head = p.head[n] + head_fixup;
-        xt = *reinterpret_cast<const int4 *>(p.xtab + tid % ow);
-        const int4 yt0 = *reinterpret_cast<const int4 *>(p.ytab + min(tid, oh - 1));
+        int4 yt0 = make_int4(0, 0, 0, 0);
+        if (MODE == AGX_OUT_RESIZE) {
+            xt = *reinterpret_cast<const int4 *>(p.xtab + tid % ow);
+            yt0 = *reinterpret_cast<const int4 *>(p.ytab + min(tid, oh - 1));
+        }
         compute_loc(p, lin, oh - fh, ow - fw, r, c);
         r = __builtin_amdgcn_readfirstlane(r);
         c = __builtin_amdgcn_readfirstlane(c);
@@ -117,16 +120,18 @@ __device__ __forceinline__ void fovea_fixed_body(const G g, const FovParams &p, 
                 p.user_loc[2 * n + 1] = c;
             }
         }
-        if (tid < oh) *reinterpret_cast<int4 *>(ytab_s + tid) = yt0;
-        for (int i = tid + kThreads; i < oh; i += kThreads) ytab_s[i] = p.ytab[i];
+        if (MODE == AGX_OUT_RESIZE) {
+            if (tid < oh) *reinterpret_cast<int4 *>(ytab_s + tid) = yt0;
+            for (int i = tid + kThreads; i < oh; i += kThreads) ytab_s[i] = p.ytab[i];
+        }
 #pragma unroll
         for (int k = 0; k < kW; ++k)
             if (tid + k * kThreads < wwords) reinterpret_cast<uint32_t *>(raw)[tid + k * kThreads] = ww[k];
         for (int i = tid + kW * kThreads; i < wwords; i += kThreads)
             reinterpret_cast<uint32_t *>(raw)[i] = COHERENT ? __hip_atomic_load(wsrc + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : wsrc[i];
         __syncthreads();
-        r = 0;                                                        // the LDS image starts at the window's first row
     }
+    const int r_img = kWindowOnly ? r : 0;                            // frame row held by row 0 of the LDS image
     const int xcol = tid % ow, yb = tid / ow;                         // phase-C column / first row
     if (!kWindowOnly) {
     const int fwords = fbytes >> 2;
@@ -177,12 +182,12 @@ __device__ __forceinline__ void fovea_fixed_body(const G g, const FovParams &p, 
     AGX_STAMP(2);
 
     }
-    const unsigned char *win = raw + r * ow + c;                      // window origin inside the frame
+    const unsigned char *win = raw + (r - r_img) * ow + c;            // window origin inside the LDS image
     if (MODE == AGX_OUT_RAW) {
         float *out = p.obs + ((size_t)n * p.fs + j) * (size_t)(fh * fw);
         for (int i = tid; i < fh * fw; i += kThreads) {
             const int y = i / fw, x = i - y * fw;
-            out[i] = lut[win[y * ow + x]];
+            out[i] = unit_fast((float)win[y * ow + x]);
         }
         return;
     }
@@ -193,10 +198,10 @@ __device__ __forceinline__ void fovea_fixed_body(const G g, const FovParams &p, 
             const int row = q / ow4, x = (q - row * ow4) * 4;
             float v[4] = {0.f, 0.f, 0.f, 0.f};
             if (row >= r && row < r + fh && x + 3 >= c && x < c + fw) {
-                const uint32_t w = *reinterpret_cast<const uint32_t *>(raw + row * ow + x);
+                const uint32_t w = *reinterpret_cast<const uint32_t *>(raw + (row - r_img) * ow + x);
 #pragma unroll
                 for (int k = 0; k < 4; ++k)
-                    if (x + k >= c && x + k < c + fw) v[k] = lut[(w >> (8 * k)) & 0xFF];
+                    if (x + k >= c && x + k < c + fw) v[k] = unit_fast((float)((w >> (8 * k)) & 0xFF));
             }
             store_obs(&out4[q], make_float4(v[0], v[1], v[2], v[3]));
         }
@@ -218,7 +223,7 @@ __device__ __forceinline__ void fovea_fixed_body(const G g, const FovParams &p, 
         for (int i = tid; i < fh * ow; i += kThreads) {
             const int y = i / ow, x = i - y * ow;
             const Tap t = p.xtab[x];
-            H[i] = fmaf(t.b, lut[win[y * ow + t.aux]], t.a * lut[win[y * ow + t.lo]]);
+            H[i] = fmaf(t.b, unit_fast((float)win[y * ow + t.aux]), t.a * unit_fast((float)win[y * ow + t.lo]));
         }
     }
     __syncthreads();
