@@ -208,7 +208,11 @@ class FlexibleFovealEnv(FixedFovealEnv):
     def _obs(self, obs, info):
         # raw crops are ragged (fov_env.py:283-298): the core packs them (args.ragged_obs = "packed", set in __init__), so
         # obs[0] already is the [fs, res_h, res_w] view - no padded buffer to slice
-        return obs[0]
+        o = obs[0]
+        if not (self.mask_out or self.resize_to_full) and not getattr(self._core(), "_ragged_packed", False):
+            rh, rw = (int(v) for v in info["fov_res"])          # a core built from another args object: padded batch
+            o = o[..., :rh, :rw]
+        return o
 
     def _action(self, action):
         a = super()._action(action)

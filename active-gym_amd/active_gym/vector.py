@@ -302,7 +302,7 @@ class AtariVecEnv:
             off = self._poff.cpu().numpy()
             res = self._res.cpu().numpy()
             flat = self._packed[:int(off[-1])]
-            flat = flat.cpu().numpy() if self._numpy_out else (flat.clone() if self._copy_obs else flat)
+            flat = flat.cpu().numpy() if self._numpy_out else flat.clone()   # (the packed buffer is not double-buffered)
             return [flat[int(off[i]):int(off[i + 1])].reshape(self.frame_stack, int(res[i, 0]), int(res[i, 1]))
                     for i in range(self.num_envs)]
         if self._numpy_out:
