@@ -92,3 +92,29 @@ def test_flexible_full_size(dev, aa):
         worst = max(worst, torch.stack(errs).max().item())
         assert worst <= FLOAT_TOL, (step, worst)
     p.close()
+
+
+def test_large_batch_every_env_is_reached(dev):
+    """N = 20,000 envs in one context (gridDim.y carries the env index; the ABI allows up to 65,535): constant-colour
+    screens give every env - first, last, and a sample in between - its own constant observation, and fov_loc follows the
+    NumPy rule for all of them."""
+    from active_gym import ObsPipeline
+    from oracle import oracle as O
+    n = 20000
+    p = ObsPipeline(num_envs=n, kind="fixed", obs_size=(OBS, OBS), fov_size=(FOV, FOV), frame_stack=2, fov_init_loc=(0, 0),
+                    sensory_action_mode="absolute", resize_to_full=True, device=dev)
+    g = torch.Generator(device="cpu").manual_seed(9)
+    cols = torch.randint(0, 256, (n, 3), generator=g, dtype=torch.uint8)
+    frames = cols.view(n, 1, 1, 1, 3).to(dev).expand(n, 2, 210, 160, 3).contiguous()
+    cmd = torch.full((n,), 2, dtype=torch.uint8, device=dev)
+    for _ in range(2):
+        p.ingest(frames, cmd)
+    del frames
+    a = torch.rand((n, 2), generator=g) * 65 - 5
+    obs, loc = p.fovea(a.to(dev))
+    lum = torch.from_numpy(O.ale_luminance(cols.numpy())).to(dev)
+    want = (lum.float() / 255.0).view(n, 1, 1, 1)
+    assert (obs - want).abs().max().item() <= 2e-7
+    assert torch.equal(p.stack_u8(), lum.view(n, 1, 1, 1).expand(n, 2, OBS, OBS))
+    assert np.array_equal(loc.cpu().numpy(), np.rint(np.clip(a.numpy().astype(np.float64), 0, OBS - FOV)).astype(np.int32))
+    p.close()
