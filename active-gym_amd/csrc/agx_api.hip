@@ -29,6 +29,9 @@ struct agx_ctx {
     int cur_fov = 0;
     int2 *in_xtab = nullptr;   // K1 tables
     int4 *in_ytab = nullptr;
+    int2 *in_xtab12 = nullptr; // K1 band12 form: {2 * x0, (a0 | a1 << 16) << 4} / {b0 << 8, b1 << 8}
+    int2 *in_ytab12 = nullptr;
+    bool band12_ok = false;    // 12-row bands all full, affine source rows, every x tap pair adjacent
     Tap *fx_xtab = nullptr;    // K2 tables
     Tap *fx_ytab = nullptr;
     int2 *per_ln[4] = {nullptr, nullptr, nullptr, nullptr};   // K3 tables
@@ -42,7 +45,12 @@ struct agx_ctx {
     // K4 resize_to_full form (k_fovea_flexible3): composed per-axis operators, see agx_k4_flex3.h
     Flex3Params f3{};
     bool f3_ok = false;
-    int64_t *pack_sizes = nullptr;   // agx_fovea_flexible_packed: [N] crop sizes (allocated on first use)
+    // K4 raw-crop / mask-out / packed forms (k_fovea_flexible_raw3, agx_k4_raw3.h)
+    FlexRawParams fr{};
+    bool fr_ok = false;
+    size_t fr_lds = 0;
+    int64_t *pack_local = nullptr;   // agx_fovea_flexible_packed: [N] block-local exclusive offsets, [ceil(N/1024)] block totals
+    int64_t *pack_block = nullptr;   // (both allocated in agx_create for flexible raw-crop contexts: no allocation in a step call)
     // K3 tuned form 3 (k_fovea_peripheral3)
     Per3Params p3{};
     int p3_mt = 0;
@@ -332,7 +340,7 @@ int agx_destroy(agx_ctx *ctx) {
     if (!ctx) return AGX_OK;
     DeviceGuard g(ctx->cfg.device);
     void *ptrs[] = {ctx->ring, ctx->head[0], ctx->head[1], ctx->loc[0], ctx->loc[1], ctx->res[0], ctx->res[1],
-                    ctx->in_xtab, ctx->in_ytab, ctx->fx_xtab, ctx->fx_ytab,
+                    ctx->in_xtab, ctx->in_ytab, ctx->in_xtab12, ctx->in_ytab12, ctx->fx_xtab, ctx->fx_ytab,
                     ctx->per_ln[0], ctx->per_ln[1], ctx->per_ln[2], ctx->per_ln[3],
                     ctx->per_w[0], ctx->per_w[1], ctx->per_w[2], ctx->per_w[3],
                     ctx->flex_ln[0], ctx->flex_ln[1], ctx->flex_ln[2], ctx->flex_ln[3], ctx->flex_ln[4], ctx->flex_ln[5],
@@ -467,6 +475,17 @@ int agx_create(const agx_config *cfg, agx_ctx **out) {
         }
         if ((rc = upload(ctx, &ctx->in_xtab, xt)) != AGX_OK) return bail(rc);
         if ((rc = upload(ctx, &ctx->in_ytab, yt)) != AGX_OK) return bail(rc);
+        // band12 form: the same coefficients in the shape its phase 2 consumes
+        std::vector<int2> xt12(c.obs_w), yt12(c.obs_h);
+        bool adjacent = true;
+        for (int i = 0; i < c.obs_w; ++i) {
+            adjacent = adjacent && x1[i] == x0[i] + 1;
+            xt12[i] = make_int2(2 * x0[i], (int)((((uint32_t)a0[i] & 0xFFFFu) | ((uint32_t)a1[i] << 16)) << 4));
+        }
+        for (int i = 0; i < c.obs_h; ++i) yt12[i] = make_int2(b0[i] << 8, b1[i] << 8);
+        if ((rc = upload(ctx, &ctx->in_xtab12, xt12)) != AGX_OK) return bail(rc);
+        if ((rc = upload(ctx, &ctx->in_ytab12, yt12)) != AGX_OK) return bail(rc);
+        ctx->band12_ok = adjacent && ctx->y_affine && c.obs_h % 12 == 0 && (c.obs_w / 4) * 12 <= kThreads;
         // ingest workgroup: T threads produce band_rows output rows (band_rows * ow/4 <= T and the
         // 2 * band_rows row jobs fit the T/40 loader groups x 4 iterations).  128-thread workgroups give
         // 16 independent workgroups per CU whose load / compute phases interleave (AGX_INGEST_T tunes).
@@ -532,6 +551,31 @@ int agx_create(const agx_config *cfg, agx_ctx **out) {
                 q.r1_bytes = f3.r1_bytes;
                 q.dp = f3.dp;
                 ctx->f3_ok = true;
+            }
+            // raw-crop / mask-out: the composed squeeze-and-back form where its plan applies
+            const FlexRawHost fr = build_flexraw(c);
+            if (fr.ok && fr.lds(c) <= kMaxLds) {
+                FlexRawParams &q = ctx->fr;
+                if ((rc = upload_owned(ctx, &q.wb_meta, fr.wb_meta)) != AGX_OK) return bail(rc);
+                if ((rc = upload_owned(ctx, &q.wb_lo, fr.wb_lo)) != AGX_OK) return bail(rc);
+                if ((rc = upload_owned(ctx, &q.wb_w, fr.wb_w)) != AGX_OK) return bail(rc);
+                if ((rc = upload_owned(ctx, &q.hd_meta, fr.hd_meta)) != AGX_OK) return bail(rc);
+                if ((rc = upload_owned(ctx, &q.hd_lo, fr.hd_lo)) != AGX_OK) return bail(rc);
+                if ((rc = upload_owned(ctx, &q.hd_w, fr.hd_w)) != AGX_OK) return bail(rc);
+                if ((rc = upload_owned(ctx, &q.hb, fr.hb)) != AGX_OK) return bail(rc);
+                q.r0_bytes = fr.r0_bytes;
+                q.r1_bytes = fr.r1_bytes;
+                q.dp = fr.dp;
+                q.n_envs = c.num_envs;
+                ctx->fr_lds = fr.lds(c);
+                ctx->fr_ok = true;
+            }
+            if (c.out_mode == AGX_OUT_RAW) {       // the packed form's scan buffers
+                const size_t nb = (N + kScanEnvsPerBlock - 1) / kScanEnvsPerBlock;
+                TRY(hipMalloc(reinterpret_cast<void **>(&ctx->pack_local), N * sizeof(int64_t)));
+                ctx->owned.push_back(ctx->pack_local);
+                TRY(hipMalloc(reinterpret_cast<void **>(&ctx->pack_block), nb * sizeof(int64_t)));
+                ctx->owned.push_back(ctx->pack_block);
             }
         }
         if (c.kind == AGX_KIND_PERIPHERAL) {
@@ -642,6 +686,9 @@ static IngestParams ingest_params(agx_ctx *ctx, const uint8_t *d_frames, const u
     p.y_add = ctx->y_add;
     p.y_shift = ctx->y_shift;
     p.nbands = (c.obs_h + ctx->band_rows - 1) / ctx->band_rows;
+    p.xtab12 = ctx->in_xtab12;
+    p.ytab12 = ctx->in_ytab12;
+    p.ow4_inv16 = (65536 + c.obs_w / 4 - 1) / (c.obs_w / 4);
     p.stamps = nullptr;
 #ifdef AGX_STAMPS
     if (const char *e = getenv("AGX_DBG_PTR")) p.stamps = reinterpret_cast<unsigned long long *>(strtoull(e, nullptr, 0));
@@ -652,6 +699,7 @@ static IngestParams ingest_params(agx_ctx *ctx, const uint8_t *d_frames, const u
 static size_t ingest_lds(const agx_ctx *ctx) {
     return sizeof(int4) * ctx->band_rows + sizeof(int2) * ctx->cfg.obs_w + (size_t)2 * ctx->band_rows * 2 * kRawW;
 }
+static size_t band12_lds(const agx_ctx *ctx) { return sizeof(int2) * (kB12Rows + ctx->cfg.obs_w) + kB12GrayB; }
 
 int agx_ingest(agx_ctx *ctx, const uint8_t *d_frames, const uint8_t *d_cmd, void *stream) {
     if (!ctx) return AGX_E_INVALID;
@@ -688,8 +736,8 @@ int agx_ingest(agx_ctx *ctx, const uint8_t *d_frames, const uint8_t *d_cmd, void
              ctx->y_affine && ctx->band_rows == 12 && c.obs_h % 12 == 0 && (c.obs_w / 4) * 12 <= kThreads)
         AGX_LAUNCH(0, k_ingest_pair12, dim3(bands, (c.num_envs + 1) / 2), dim3(256), lds + (size_t)2 * 12 * 2 * kRawW, S(stream), p,
                    (int)c.num_envs);
-    else if (ctx->tune.no_full == 0 && ctx->y_affine && ctx->band_rows == 12 && c.obs_h % 12 == 0)
-        AGX_LAUNCH(0, k_ingest_full12, dim3(bands, c.num_envs), dim3(256), lds, S(stream), p);
+    else if (ctx->tune.no_full == 0 && ctx->band12_ok && ctx->band_rows == 12)
+        AGX_LAUNCH(0, k_ingest_full12, dim3(bands, c.num_envs), dim3(256), band12_lds(ctx), S(stream), p);
     else
         AGX_LAUNCH(0, k_ingest<256>, dim3(bands, c.num_envs), dim3(256), lds, S(stream), p);
     AGX_HIP(ctx, hipGetLastError());
@@ -710,8 +758,8 @@ int agx_ingest_gray_raw(agx_ctx *ctx, const uint8_t *d_gray, const uint8_t *d_cm
     p.band_rows = std::min(br, ctx->band_rows > 0 && ctx->ingest_t == 256 ? ctx->band_rows : br);
     p.nbands = (c.obs_h + p.band_rows - 1) / p.band_rows;
     const size_t lds = sizeof(int4) * p.band_rows + sizeof(int2) * c.obs_w + (size_t)2 * p.band_rows * 2 * kRawW;
-    if (ctx->tune.no_full == 0 && ctx->y_affine && p.band_rows == 12 && c.obs_h % 12 == 0)
-        AGX_LAUNCH(0, k_ingest_grayraw_full12, dim3(p.nbands, c.num_envs), dim3(kThreads), lds, S(stream), p);
+    if (ctx->tune.no_full == 0 && ctx->band12_ok && p.band_rows == 12)
+        AGX_LAUNCH(0, k_ingest_grayraw_full12, dim3(p.nbands, c.num_envs), dim3(kThreads), band12_lds(ctx), S(stream), p);
     else
         AGX_LAUNCH(0, k_ingest_grayraw, dim3(p.nbands, c.num_envs), dim3(kThreads), lds, S(stream), p);
     AGX_HIP(ctx, hipGetLastError());
@@ -1173,6 +1221,17 @@ int agx_fovea_flexible(agx_ctx *ctx, const void *d_action, int action_dtype, con
             AGX_LAUNCH(1, (k_fovea_flexible3<GS>), grid, block, lds3, S(stream), GS{}, ctx->f3, p);
         else
             AGX_LAUNCH(1, (k_fovea_flexible3<GeomR>), grid, block, lds3, S(stream), gr, ctx->f3, p);
+    } else if (!generic_only && ctx->fr_ok && ctx->tune.flex_v2 == 0 && c.out_mode != AGX_OUT_RESIZE) {
+        const dim3 grid(c.frame_stack, c.num_envs), block(kThreads);
+        using GS = GeomS<84, 84, 30, 30>;
+        const bool headline = c.obs_h == 84 && c.obs_w == 84 && c.fov_h == 30 && c.fov_w == 30;
+        if (c.out_mode == AGX_OUT_MASK) {
+            if (headline) AGX_LAUNCH(1, (k_fovea_flexible_raw3<GS, AGX_OUT_MASK>), grid, block, ctx->fr_lds, S(stream), GS{}, ctx->fr, p);
+            else AGX_LAUNCH(1, (k_fovea_flexible_raw3<GeomR, AGX_OUT_MASK>), grid, block, ctx->fr_lds, S(stream), gr, ctx->fr, p);
+        } else {
+            if (headline) AGX_LAUNCH(1, (k_fovea_flexible_raw3<GS, AGX_OUT_RAW>), grid, block, ctx->fr_lds, S(stream), GS{}, ctx->fr, p);
+            else AGX_LAUNCH(1, (k_fovea_flexible_raw3<GeomR, AGX_OUT_RAW>), grid, block, ctx->fr_lds, S(stream), gr, ctx->fr, p);
+        }
     } else if (!generic_only && lds2 <= kMaxLds) {
         FlexParams g;
         TabFamily *fam[6] = {&g.wd, &g.wb, &g.wf, &g.hd, &g.hb, &g.hf};
@@ -1204,28 +1263,43 @@ int agx_fovea_flexible_packed(agx_ctx *ctx, const void *d_action, int action_dty
     int rc = check_dt(ctx, d_action, action_dtype);
     if (rc) return rc;
     DeviceGuard g(c.device);
-    if (!ctx->pack_sizes) {
-        AGX_HIP(ctx, hipMalloc(reinterpret_cast<void **>(&ctx->pack_sizes), (size_t)c.num_envs * sizeof(int64_t)));
-        ctx->owned.push_back(ctx->pack_sizes);
-    }
-    // launch 1: every env's new fov_loc / fov_res (fov_env.py:300-324) and its crop size; launch 2: offsets
-    FlexStateParams q;
+    // launch 1: every env's new fov_loc / fov_res (fov_env.py:300-324), its crop size, and level 1 of the exclusive scan
+    // (block-local offsets + block totals; the buffers belong to the context since agx_create)
+    FlexScanParams q;
     q.f = fov_params(ctx, d_action, action_dtype, d_action_type, nullptr, nullptr, d_fov_loc, d_fov_res);
-    q.sizes = ctx->pack_sizes;
+    q.local_off = ctx->pack_local;
+    q.block_tot = ctx->pack_block;
     q.n = c.num_envs;
     q.oh = c.obs_h;
     q.ow = c.obs_w;
-    hipLaunchKernelGGL(k_flex_state, dim3((c.num_envs + kThreads - 1) / kThreads), dim3(kThreads), 0, S(stream), q);
-    hipLaunchKernelGGL(k_scan_sizes, dim3(1), dim3(1024), 0, S(stream), ctx->pack_sizes, d_offsets, (int)c.num_envs);
+    const int nb = (c.num_envs + kScanEnvsPerBlock - 1) / kScanEnvsPerBlock;
+    hipLaunchKernelGGL(k_flex_state_scan, dim3(nb), dim3(kThreads), 0, S(stream), q);
     AGX_HIP(ctx, hipGetLastError());
-    ctx->cur_fov ^= 1;
-    // launch 3: the crops (squeezed to fov_size and back iff rows > fov rows, fov_env.py:283-287) at their offsets; the
-    // state is final, so the crop kernel runs with no action and writes the same state through
+    ctx->cur_fov ^= 1;                   // the state is final from here on; the crop launch only reads it
+    // launch 2: the crops (squeezed to fov_size and back iff rows > fov rows, fov_env.py:283-287) at their offsets
     FovParams p = fov_params(ctx, nullptr, 0, nullptr, nullptr, d_packed, nullptr, nullptr);
     p.packed = d_packed;
     p.packed_off = d_offsets;
     p.packed_cap = capacity_floats;
     const GeomR gr{c.obs_h, c.obs_w, c.fov_h, c.fov_w};
+    if (ctx->fr_ok && ctx->tune.generic == 0 && ctx->tune.flex_v2 == 0) {
+        FlexRawParams fr = ctx->fr;
+        fr.local_off = ctx->pack_local;
+        fr.block_tot = ctx->pack_block;
+        fr.offsets = d_offsets;
+        const dim3 grid(c.frame_stack, c.num_envs), block(kThreads);
+        using GS = GeomS<84, 84, 30, 30>;
+        if (c.obs_h == 84 && c.obs_w == 84 && c.fov_h == 30 && c.fov_w == 30)
+            AGX_LAUNCH(1, (k_fovea_flexible_raw3<GS, kRawPacked>), grid, block, ctx->fr_lds, S(stream), GS{}, fr, p);
+        else
+            AGX_LAUNCH(1, (k_fovea_flexible_raw3<GeomR, kRawPacked>), grid, block, ctx->fr_lds, S(stream), gr, fr, p);
+        AGX_HIP(ctx, hipGetLastError());
+        return AGX_OK;
+    }
+    // geometries outside the raw3 plan: offsets as a launch of their own, then the pass-by-pass crop kernel, which writes
+    // the (unchanged) state through into the other half of the double buffer
+    hipLaunchKernelGGL(k_flex_finish_offsets, dim3((c.num_envs + 1 + kThreads - 1) / kThreads), dim3(kThreads), 0, S(stream),
+                       ctx->pack_local, ctx->pack_block, d_offsets, (int)c.num_envs);
     const size_t lds2 = flex2_lds(c, ctx->flex_tab_floats);
     if (ctx->tune.generic == 0 && lds2 <= kMaxLds) {
         FlexParams fp;

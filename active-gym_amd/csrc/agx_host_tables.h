@@ -9,6 +9,7 @@
 #include "agx_common.h"
 #include "agx_k3_per3.h"
 #include "agx_k4_flex3.h"
+#include "agx_k4_raw3.h"
 #include "agx_rows.h"
 
 namespace agx {
@@ -107,6 +108,70 @@ inline Flex3Host build_flex3(const agx_config &c) {
 
 inline size_t flex3_lds(const Flex3Host &h, const agx_config &c) { return h.lds() + (size_t)c.obs_h * sizeof(int4); }
 
+
+// ---- K4 raw-crop / mask-out / packed forms (agx_k4_raw3.h): the squeeze-and-expand-back chain of fov_env.py:276-287
+// composed per axis: H squeeze (shared shape with Flex3Host), W (Wbck Wdwn)(rw): rw -> rw, H expand back fh -> rh
+struct FlexRawHost {
+    bool ok = false;
+    std::vector<int2> wb_meta, hd_meta;
+    std::vector<int32_t> wb_lo, hd_lo;
+    std::vector<float> wb_w, hd_w;
+    std::vector<Tap> hb;
+    int r0_bytes = 0, r1_bytes = 0, dp = 0;
+    size_t lds(const agx_config &c) const { return (size_t)r0_bytes + r1_bytes + (size_t)c.obs_h * sizeof(Tap); }
+};
+
+inline FlexRawHost build_flexraw(const agx_config &c) {
+    using namespace agx::rows;
+    FlexRawHost h;
+    const int oh = c.obs_h, ow = c.obs_w, fh = c.fov_h, fw = c.fov_w;
+    const bool aa = c.antialias != 0;
+    if (c.out_mode == AGX_OUT_RESIZE || ow > kThreads || fh > kThreads / 8 || oh > 1024) return h;
+    const int rstep = kThreads / ow;
+    const int erows = (fh + rstep - 1) / rstep * rstep;
+    h.dp = (ow + 7) & ~7;
+    h.r0_bytes = (int)((std::max((size_t)oh * ow + 8 * (size_t)ow + 32, (size_t)erows * ow * 4) + 15) & ~(size_t)15);
+    h.r1_bytes = (int)(((size_t)erows * h.dp * 4 + 15) & ~(size_t)15);
+    h.wb_meta.assign(ow + 1, make_int2(4, 0));
+    h.wb_lo.assign((size_t)(ow + 1) * ow, 0);
+    h.hd_meta.assign(oh + 1, make_int2(4, 0));
+    h.hd_lo.assign((size_t)(oh + 1) * fh, 0);
+    h.hb.assign((size_t)(oh + 1) * oh, Tap{0, 0, 0.f, 0.f});
+    for (int rw = 1; rw <= ow; ++rw) {
+        Op comp = compose(resize_axis(fw, rw, aa), resize_axis(rw, fw, aa));      // rw -> fw -> rw
+        const int T = flex3_bucket(max_taps(comp), 16);
+        if (!T) return h;
+        fit(comp, rw, T);
+        h.wb_meta[rw] = make_int2(T, (int)h.wb_w.size());
+        for (int x = 0; x < ow; ++x) {
+            h.wb_lo[(size_t)rw * ow + x] = x < rw ? comp[x].lo : 0;
+            for (int q = 0; q < T; ++q) h.wb_w.push_back(x < rw && q < (int)comp[x].w.size() ? (float)comp[x].w[q] : 0.f);
+        }
+    }
+    for (int rh = fh + 1; rh <= oh; ++rh) {
+        Op d = resize_axis(rh, fh, aa);
+        const int T = flex3_bucket(max_taps(d), 8);
+        if (!T) return h;
+        fit(d, rh, T);
+        h.hd_meta[rh] = make_int2(T, (int)h.hd_w.size());
+        for (int y = 0; y < fh; ++y) {
+            h.hd_lo[(size_t)rh * fh + y] = d[y].lo;
+            for (int q = 0; q < T; ++q) h.hd_w.push_back(q < (int)d[y].w.size() ? (float)(d[y].w[q] / 255.0) : 0.f);
+        }
+        const Op back = resize_axis(fh, rh, aa);                                  // an up-scale: one or two taps
+        for (int y = 0; y < rh; ++y) {
+            Row r = back[y];
+            trim(r);
+            if (r.w.size() > 2) return h;
+            const bool two = r.w.size() > 1;
+            h.hb[(size_t)rh * oh + y] = Tap{r.lo, two ? r.lo + 1 : r.lo, (float)r.w[0], two ? (float)r.w[1] : 0.f};
+        }
+    }
+    if (h.wb_w.empty()) h.wb_w.push_back(0.f);
+    if (h.hd_w.empty()) h.hd_w.assign(4, 0.f);
+    h.ok = true;
+    return h;
+}
 
 // ---- K3 tuned form 3 (agx_k3_per3.h): the four passes' taps, the squeeze tables padded to one compile-time bound
 struct Per3Host {

@@ -106,6 +106,10 @@ struct IngestParams {
     // y0(dy) == (dy * y_mul + y_add) >> y_shift and y1 == min(y0 + 1, raw_h - 1) for every dy (checked
     // exhaustively against ytab at agx_create); lets the frame loads start without a table round trip.
     int32_t y_affine, y_mul, y_add, y_shift;
+    // band12 form (ingest_band12): phase-2 tables prepared on the host and the thread -> (row, column quad) divider
+    const int2 *xtab12;      // [ow]  {2 * x0 (byte offset of the tap pair in a u16 gray row), (a0 | a1 << 16) << 4}
+    const int2 *ytab12;      // [oh]  {b0 << 8, b1 << 8}
+    int32_t ow4_inv16;       // ceil(65536 / (ow / 4)): tid / (ow / 4) == (tid * ow4_inv16) >> 16 for tid < 256
     unsigned long long *stamps;   // diagnostic builds only (AGX_STAMPS): [workgroup][wave][8] records
 };
 
@@ -328,6 +332,249 @@ __device__ __forceinline__ void ingest_band(const IngestParams &p, const int ban
     ingest_band<T, GRAY, FBR>(p, band, n, smem, (int)threadIdx.x);
 }
 
+
+// ---------------------------------------------------------------------------------------------
+// K1, band12 form (round 3) - the kernel of the headline geometry.  Same work split as ingest_band<256, GRAY, 12>
+// (12-row bands, all full; affine source rows; 240 loader threads x 8 pieces) with a shorter instruction stream:
+//
+// * luminance: T8 = 8 t = 8 (2989 r + 5870 g + 1140 b + 5000) straight from the two v_dot4_u32_u8 (weights
+//   8 * (2989, 5870, 1140) = 256 * (93, 183, 35) + (104, 112, 160), constant 40000 = 256 * 156 + 64), then ONE
+//   v_mul_hi_u32 by ceil(2^45 / 10^4): X = floor(t * 65536 / 10^4 + e), 0 <= e < 2^-7, so byte 2 of X is
+//   q = floor(t / 10^4) exactly (the largest fraction, 9999 / 10^4 * 65536 + e, stays below 65536), byte 3 is 0 and the
+//   low 16 bits are 0 exactly when t is a multiple of 10^4 - the exact .5 ties, the only inputs where ALE's double
+//   expression can differ (a remainder m > 0 leaves floor(6.55 m) >= 6 there).  All 2^24 triples checked on the host
+//   (tests/test_oracle_resize.py::test_band12_luminance_arithmetic) and on the device.  No shift, no remainder
+//   multiply: q is already byte-aligned and the tie test is a packed 16-bit minimum over the X of a row job.
+// * gray goes to LDS as u16 [frame][row][top | bottom][160]: one v_perm_b32 per two pixels builds the 16-bit lanes that
+//   v_dot2_u32_u16 wants, so phase 2 reads every horizontal tap pair (x0, x0 + 1 - adjacent for every down-scaling
+//   geometry, checked at agx_create) with ONE ds_read_b32 at a 2-byte-aligned address and needs no byte shuffling.
+// * everything phase 1 writes is written unconditionally (a frame that was not sampled is left out in phase 2, by a
+//   wave-uniform branch on nvalid): no per-job destination predicate.
+// ---------------------------------------------------------------------------------------------
+constexpr uint32_t kLum8Lo = 104u | (112u << 8) | (160u << 16);
+constexpr uint32_t kLum8Hi = 93u | (183u << 8) | (35u << 16);
+constexpr uint32_t kLumM13 = 3518437209u;                                 // ceil(2^45 / 10^4)
+
+template <int SH = 0>      // SH = 1: the pixel sits in bytes 1..3 of `px`
+__device__ __forceinline__ uint32_t lum_x(uint32_t px) {
+    const uint32_t hi = __builtin_amdgcn_udot4(px, kLum8Hi << (8 * SH), 156u, false);
+    const uint32_t t8 = __builtin_amdgcn_udot4(px, kLum8Lo << (8 * SH), (hi << 8) + 64u, false);
+    return __umulhi(t8, kLumM13);
+}
+__device__ __forceinline__ uint32_t pk_min_u16(uint32_t a, uint32_t b) {
+    uint32_t r;
+    asm("v_pk_min_u16 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+// ALE's double expression for a pixel on an exact tie (operation order of ColourPalette, no fused multiply-add)
+__device__ __forceinline__ uint32_t ale_lum_tie(uint32_t r, uint32_t g, uint32_t b) {
+#pragma clang fp contract(off)
+    const double x = ((double)r * 0.2989 + (double)g * 0.5870) + (double)b * 0.1140;
+    const double fl = floor(x);
+    return (uint32_t)fl + (((x - fl) >= 0.5) ? 1u : 0u);
+}
+struct __attribute__((packed, aligned(4))) U2a4 { uint32_t x, y; };      // two dwords at a 4-byte-aligned LDS address
+
+constexpr int kB12Rows = 12;
+constexpr uint32_t kB12RowB = kRawW * 2;                                  // one u16 gray row
+constexpr uint32_t kB12JobB = 2 * kB12RowB;                               // top + bottom source row of one output row
+constexpr uint32_t kB12FrameB = kB12Rows * kB12JobB;
+constexpr uint32_t kB12GrayB = 2 * kB12FrameB;                            // 15,360 B
+
+// LDS: ytab12[12] int2 | xtab12[ow] int2 | gray16 [2][12][2][160] u16
+template <bool GRAY>
+__device__ __forceinline__ void ingest_band12(const IngestParams &p, const int band, const int n, unsigned char *smem,
+                                              const int tid) {
+    constexpr int T = kThreads;
+    (void)T;
+    AGX_STAMP(0);
+    constexpr uint32_t kRowB = GRAY ? kRawW : kRawRowBytes;
+    constexpr uint32_t kFrameB = kRawH * kRowB;
+    constexpr int G4 = kRawW / 4, RG = kThreads / G4;                     // 40 pieces per row, 6 row groups
+    const int dy0 = band * kB12Rows;
+    int2 *ytab_s = reinterpret_cast<int2 *>(smem);
+    int2 *xtab_s = ytab_s + kB12Rows;
+    unsigned char *gray = smem + sizeof(int2) * (kB12Rows + p.ow);
+    const uint8_t *f0 = p.frames + (size_t)n * 2 * kFrameB;               // wave-uniform bases of the two sampled screens
+    const uint8_t *f1 = f0 + kFrameB;
+    const int rg = tid / G4, g4 = tid - rg * G4;
+    const bool loader = rg < RG;                                          // 240 of the 256 threads
+    // phase 1 loads: row job `it` = (frame it / 2, output row rg + 6 * (it % 2)); both source rows, 4 pixels wide.
+    // Issued before the command byte is known, as if both frames were sampled.
+    U3 w0[4], w1[4];                                                      // GRAY uses .x only
+    uint32_t dstb = 0;
+    if (loader) {
+        const uint32_t col = g4 * (GRAY ? 4 : 12);
+        uint32_t o0[2], o1[2];
+#pragma unroll
+        for (int itl = 0; itl < 2; ++itl) {
+            const uint32_t dy = (uint32_t)(dy0 + rg + RG * itl);
+            const int y0 = (int)(mul_u24(dy, (uint32_t)p.y_mul) + (uint32_t)p.y_add) >> p.y_shift;
+            const int y1 = min(y0 + 1, kRawH - 1);
+            o0[itl] = mad_u24((uint32_t)y0, kRowB, col);
+            o1[itl] = mad_u24((uint32_t)y1, kRowB, col);
+        }
+#pragma unroll
+        for (int it = 0; it < 4; ++it) {
+            const uint8_t *fb = it < 2 ? f0 : f1;
+            if (GRAY) {
+                w0[it].x = *reinterpret_cast<const uint32_t *>(fb + o0[it & 1]);
+                w1[it].x = *reinterpret_cast<const uint32_t *>(fb + o1[it & 1]);
+            } else {
+                w0[it] = load_piece(fb + o0[it & 1]);
+                w1[it] = load_piece(fb + o1[it & 1]);
+            }
+        }
+        dstb = mad_u24((uint32_t)rg, kB12JobB, (uint32_t)g4 * 8u);
+    }
+    // phase-2 tables of this band: requested after the pieces (vmcnt retires in order), parked in LDS after the luminance
+    const int2 yt_own = *reinterpret_cast<const int2 *>(reinterpret_cast<const char *>(p.ytab12 + dy0) + 8u * (uint32_t)min(tid, kB12Rows - 1));
+    const int2 xt_own = *reinterpret_cast<const int2 *>(reinterpret_cast<const char *>(p.xtab12) + 8u * (uint32_t)min(tid, p.ow - 1));
+    const uint32_t cmd = uniform_load_u8(p.cmd + n);
+    const int head = uniform_load_i32(p.head_in + n);
+    const bool skip = (cmd & AGX_CMD_SKIP) != 0;
+    const bool clear = (cmd & AGX_CMD_CLEAR) != 0;
+    if (band == 0 && tid == 0) p.head_out[n] = skip ? head : (clear ? 0 : (head + 1 == p.fs ? 0 : head + 1));
+    if (skip) return;
+    const int nvalid = min((int)(cmd & AGX_CMD_NVALID_MASK), 2);
+    const int slot = clear ? p.fs - 1 : head;
+    AGX_STAMP(1);
+    if (nvalid > 0) {
+        if (loader) {
+            uint32_t ties = 0;
+#pragma unroll
+            for (int it = 0; it < 4; ++it) {
+                // LDS byte offset of this job's top row: frame it / 2, output row rg + 6 * (it % 2), column 4 g4
+                const uint32_t d = dstb + (uint32_t)(it >> 1) * kB12FrameB + (uint32_t)(it & 1) * (RG * kB12JobB);
+                uint2 top, bot;
+                if (GRAY) {
+                    top.x = __builtin_amdgcn_perm(0u, w0[it].x, 0x0C010C00u);
+                    top.y = __builtin_amdgcn_perm(0u, w0[it].x, 0x0C030C02u);
+                    bot.x = __builtin_amdgcn_perm(0u, w1[it].x, 0x0C010C00u);
+                    bot.y = __builtin_amdgcn_perm(0u, w1[it].x, 0x0C030C02u);
+                } else {
+                    // the 8 pixels of the job, stage by stage (8 independent chains: a v_dot4 result needs three wait
+                    // states before the next VALU instruction may read it, and the chains fill them for one another)
+                    const uint32_t px[8] = {w0[it].x, __builtin_amdgcn_alignbyte(w0[it].y, w0[it].x, 3),
+                                            __builtin_amdgcn_alignbyte(w0[it].z, w0[it].y, 2), w0[it].z,
+                                            w1[it].x, __builtin_amdgcn_alignbyte(w1[it].y, w1[it].x, 3),
+                                            __builtin_amdgcn_alignbyte(w1[it].z, w1[it].y, 2), w1[it].z};
+                    uint32_t X[8];
+#pragma unroll
+                    for (int j = 0; j < 8; ++j)
+                        X[j] = __builtin_amdgcn_udot4(px[j], (j & 3) == 3 ? kLum8Hi << 8 : kLum8Hi, 156u, false);
+#pragma unroll
+                    for (int j = 0; j < 8; ++j)
+                        X[j] = __builtin_amdgcn_udot4(px[j], (j & 3) == 3 ? kLum8Lo << 8 : kLum8Lo, (X[j] << 8) + 64u, false);
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) X[j] = __umulhi(X[j], kLumM13);
+                    const uint32_t a0 = X[0], a1 = X[1], a2 = X[2], a3 = X[3], b0 = X[4], b1 = X[5], b2 = X[6], b3 = X[7];
+                    top.x = __builtin_amdgcn_perm(a1, a0, 0x0C060C02u);   // q(a0) | q(a1) << 16
+                    top.y = __builtin_amdgcn_perm(a3, a2, 0x0C060C02u);
+                    bot.x = __builtin_amdgcn_perm(b1, b0, 0x0C060C02u);
+                    bot.y = __builtin_amdgcn_perm(b3, b2, 0x0C060C02u);
+                    // low halves: the smallest 16-bit fraction of the 8 pixels; 0 <=> one of them is an exact tie
+                    const uint32_t m = pk_min_u16(pk_min_u16(pk_min_u16(a0, a1), pk_min_u16(a2, a3)),
+                                                  pk_min_u16(pk_min_u16(b0, b1), pk_min_u16(b2, b3)));
+                    ties |= (m & 0xFFFFu) == 0u ? (1u << it) : 0u;
+                }
+                *reinterpret_cast<uint2 *>(gray + d) = top;
+                *reinterpret_cast<uint2 *>(gray + d + kB12RowB) = bot;
+            }
+            if (!GRAY && __builtin_expect(ties != 0, 0)) {
+                // about 1e-4 of random pixels sit on an exact .5 tie (1,703 of the 2^24 triples): that job's 24 source bytes
+                // are read again (not kept in registers for this branch) and the tied pixels re-done with ALE's double
+                // expression; everything else in LDS is already right.
+#pragma nounroll
+                for (int it = 0; it < 4; ++it) {
+                    if (!((ties >> it) & 1u)) continue;
+                    const uint32_t dy = (uint32_t)(dy0 + rg + RG * (it & 1));
+                    const int y0 = (int)(mul_u24(dy, (uint32_t)p.y_mul) + (uint32_t)p.y_add) >> p.y_shift;
+                    const int y1 = min(y0 + 1, kRawH - 1);
+                    const uint8_t *fb = (it >> 1) ? f1 : f0;
+                    uint16_t *g = reinterpret_cast<uint16_t *>(gray + dstb + (uint32_t)(it >> 1) * kB12FrameB +
+                                                               (uint32_t)(it & 1) * (RG * kB12JobB));
+#pragma nounroll
+                    for (int which = 0; which < 2; ++which) {
+                        const U3 a = *reinterpret_cast<const U3 *>(fb + mad_u24((uint32_t)(which ? y1 : y0), kRowB, (uint32_t)g4 * 12u));
+                        const uint32_t px[4] = {a.x, __builtin_amdgcn_alignbyte(a.y, a.x, 3),
+                                                __builtin_amdgcn_alignbyte(a.z, a.y, 2), a.z >> 8};
+#pragma unroll
+                        for (int k = 0; k < 4; ++k)
+                            if ((lum_x(px[k]) & 0xFFFFu) == 0u)
+                                g[which * kRawW + k] = (uint16_t)ale_lum_tie(px[k] & 0xFF, (px[k] >> 8) & 0xFF, (px[k] >> 16) & 0xFF);
+                    }
+                }
+            }
+        }
+        if (tid < kB12Rows) ytab_s[tid] = yt_own;
+        if (tid < p.ow) xtab_s[tid] = xt_own;
+    }
+    AGX_STAMP(2);
+    __syncthreads();
+    AGX_STAMP(3);
+
+    // phase 2: OpenCV fixed-point bilinear of 4 adjacent output pixels + max over the sampled frames -> one ring dword
+    const int ow4 = p.ow >> 2;
+    if (tid < kB12Rows * ow4) {
+        const int dyl = (int)(mul_u24((uint32_t)tid, (uint32_t)p.ow4_inv16) >> 16);
+        const int xq = tid - dyl * ow4;
+        uint32_t packed = 0;
+        if (nvalid > 0) {
+            const int2 yt = ytab_s[dyl];
+            const uint32_t b0s = (uint32_t)yt.x, b1s = (uint32_t)yt.y;
+            const int4 xt01 = *reinterpret_cast<const int4 *>(xtab_s + xq * 4);
+            const int4 xt23 = *reinterpret_cast<const int4 *>(xtab_s + xq * 4 + 2);
+            const uint32_t xo[4] = {(uint32_t)xt01.x, (uint32_t)xt01.z, (uint32_t)xt23.x, (uint32_t)xt23.z};
+            const uint32_t xa[4] = {(uint32_t)xt01.y, (uint32_t)xt01.w, (uint32_t)xt23.y, (uint32_t)xt23.w};
+            const unsigned char *row = gray + mul_u24((uint32_t)dyl, kB12JobB);
+            typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
+            // vertical pass of one frame at tap pair k: ((b0 * (h_top >> 4)) >> 16) + ((b1 * (h_bot >> 4)) >> 16) + 2,
+            // the coefficient pair pre-scaled by 16 so that (h >> 4) << 8 is one AND and each term one v_mul_hi_u32_u24
+            auto vsum = [&](uint32_t t, uint32_t b, int k) {
+                const u16x2 aa = __builtin_bit_cast(u16x2, xa[k]);
+                const uint32_t h0 = __builtin_amdgcn_udot2(__builtin_bit_cast(u16x2, t), aa, 0u, false);
+                const uint32_t h1 = __builtin_amdgcn_udot2(__builtin_bit_cast(u16x2, b), aa, 0u, false);
+                return mul_hi_u24(b0s, h0 & 0xFFFFFF00u) + mul_hi_u24(b1s, h1 & 0xFFFFFF00u) + 2u;
+            };
+            // all tap pairs are requested before the first is used.  The pair {x0, x0 + 1} as u16 lanes is the dword at byte
+            // 2 * x0 of the row - 2-byte aligned only, and a misaligned ds_read_b32 is slow on gfx950 (measured: the kernel
+            // took 59 us with them) - so the two ALIGNED dwords around it are read (ds_read2_b32) and v_alignbit_b32 picks
+            // the pair: shift 0 for an even x0, 16 for an odd one.
+            uint32_t tp[2][4], bt[2][4];
+            auto pair = [&](const unsigned char *rowp, int k) {
+                const U2a4 d = *reinterpret_cast<const U2a4 *>(rowp + (xo[k] & ~3u));
+                return __builtin_amdgcn_alignbit(d.y, d.x, (xo[k] & 2u) << 3);
+            };
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                tp[0][k] = pair(row, k);
+                bt[0][k] = pair(row + kB12RowB, k);
+            }
+            if (nvalid > 1) {
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    tp[1][k] = pair(row + kB12FrameB, k);
+                    bt[1][k] = pair(row + kB12FrameB + kB12RowB, k);
+                }
+#pragma unroll
+                for (int k = 0; k < 4; ++k)
+                    packed |= (max(vsum(tp[0][k], bt[0][k], k), vsum(tp[1][k], bt[1][k], k)) >> 2) << (8 * k);
+            } else {
+#pragma unroll
+                for (int k = 0; k < 4; ++k) packed |= (vsum(tp[0][k], bt[0][k], k) >> 2) << (8 * k);
+            }
+        }
+        const uint32_t fsz = (uint32_t)p.oh * p.ow;
+        uint8_t *env = p.ring + (size_t)n * p.fs * fsz;                            // wave-uniform
+        const uint32_t off = mad_u24((uint32_t)(dy0 + dyl), (uint32_t)p.ow, (uint32_t)xq * 4);
+        *reinterpret_cast<uint32_t *>(env + (slot * fsz + off)) = packed;
+        if (clear)
+            for (int s = 0; s < p.fs - 1; ++s) *reinterpret_cast<uint32_t *>(env + (s * fsz + off)) = 0u;
+    }
+    AGX_STAMP(4);
+}
+
 template <int T>
 __global__ __launch_bounds__(T) void k_ingest(IngestParams p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -337,7 +584,7 @@ __global__ __launch_bounds__(T) void k_ingest(IngestParams p) {
 // the headline geometry's form: 12-row bands, all full (84 = 7 * 12), affine source rows
 __global__ __launch_bounds__(kThreads) void k_ingest_full12(IngestParams p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    ingest_band<kThreads, false, 12>(p, blockIdx.x, blockIdx.y, smem);
+    ingest_band12<false>(p, blockIdx.x, blockIdx.y, smem, (int)threadIdx.x);
 }
 
 // The same two kernels under names of their own, for the env-range parts of a split step (agx_step_fixed): a kernel
@@ -548,7 +795,7 @@ __global__ __launch_bounds__(kThreads) void k_ingest_grayraw(IngestParams p) {
 }
 __global__ __launch_bounds__(kThreads) void k_ingest_grayraw_full12(IngestParams p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    ingest_band<kThreads, true, 12>(p, blockIdx.x, blockIdx.y, smem);
+    ingest_band12<true>(p, blockIdx.x, blockIdx.y, smem, (int)threadIdx.x);
 }
 
 // ---------------------------------------------------------------------------------------------

@@ -22,4 +22,5 @@
 #include "agx_k34_resample.h"
 #include "agx_k3_per3.h"
 #include "agx_k4_flex3.h"
+#include "agx_k4_raw3.h"
 #include "agx_step_env.h"

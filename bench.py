@@ -43,7 +43,17 @@ def parse():
     ap.add_argument("--frame-format", default="rgb", choices=("rgb", "gray"),
                     help="rgb = the metric's workload (raw RGB screens, luminance on the device); gray = ALE grayscale "
                          "screens in (agx_ingest_gray_raw) - a different, lighter workload, reported for DESIGN.md only")
-    ap.add_argument("--no-events", action="store_true", help="skip per-kernel HIP events in the timed region")
+    ap.add_argument("--no-events", action="store_true", help="skip the per-kernel HIP-event sampling pass (no `roofline`)")
+    ap.add_argument("--antialias", type=int, default=1, choices=(0, 1),
+                    help="peripheral / flexible kinds: torchvision Resize's antialias setting (SURVEY.md 8d: both are sub-runs)")
+    ap.add_argument("--out", default="full", choices=("full", "packed"),
+                    help="flexible kind: full = resize_to_full (the config-4 workload); packed = the ragged raw-crop sub-run "
+                         "(agx_fovea_flexible_packed: [fs, rh, rw] crops packed back to back + offsets)")
+    ap.add_argument("--preroll", type=int, default=200,
+                    help="untimed steps run BEFORE the warmup so that a short run (the driver's --steps 20) is not timed on the "
+                         "first millisecond of an idle device (clock ramp); not part of `warmup` or `steps`")
+    ap.add_argument("--samples", type=int, default=24,
+                    help="launch pairs carrying their own HIP events in the sampling pass that FOLLOWS the timed region")
     ap.add_argument("--fused", action="store_true",
                     help="fixed kind: use agx_step_fixed's heterogeneous launch (sets AGX_STEP_FUSED=1; measured a tie)")
     ap.add_argument("--split", action="store_true",
@@ -53,9 +63,9 @@ def parse():
                     help="kernel: start/stop HIP events stamped by the launch itself (hipExtLaunchKernelGGL through "
                          "agx_profile_next: the kernel's own begin/end, what rocprofv3 reports); stream: events recorded "
                          "on the stream before/after each launch (adds the ~2-3 us dispatch gap and slows the stream)")
-    ap.add_argument("--event-every", type=int, default=16,
-                    help="bracket the kernels of every M-th timed step with HIP events (each record costs ~2-3 us of "
-                         "stream time; M=1 measures every launch)")
+    ap.add_argument("--event-every", type=int, default=4,
+                    help="sampling pass: every M-th step carries the events, the steps between run plain so that a sampled "
+                         "launch sees the same neighbours as in the timed region")
     return ap.parse_args()
 
 
@@ -78,15 +88,17 @@ def synth_inputs(torch, dev, n, pool, seed, gray=False):
     return frames, cmds, acts
 
 
-def make_pipeline(kind, n, dev):
+def make_pipeline(kind, n, dev, antialias=True, packed=False):
     from active_gym import ObsPipeline
     kw = dict(num_envs=n, obs_size=(84, 84), frame_stack=4, fov_size=(30, 30), fov_init_loc=(0, 0),
               sensory_action_mode="absolute", device=dev)
     if kind == "fixed":
         return ObsPipeline(kind="fixed", resize_to_full=True, **kw)
     if kind == "peripheral":
-        return ObsPipeline(kind="peripheral", peripheral_res=(20, 20), antialias=True, **kw)
-    return ObsPipeline(kind="flexible", resize_to_full=True, antialias=True, **kw)
+        return ObsPipeline(kind="peripheral", peripheral_res=(20, 20), antialias=antialias, **kw)
+    if packed:          # ragged raw crops (fov_env.py:283-298): neither mask_out nor resize_to_full
+        return ObsPipeline(kind="flexible", resize_to_full=False, mask_out=False, antialias=antialias, **kw)
+    return ObsPipeline(kind="flexible", resize_to_full=True, antialias=antialias, **kw)
 
 
 _CPU_CHILD = r"""
@@ -382,7 +394,8 @@ def main():
             dist.init_process_group(backend)
 
     n = args.envs
-    pipe = make_pipeline(args.kind, n, dev)
+    packed_mode = args.kind == "flexible" and args.out == "packed"
+    pipe = make_pipeline(args.kind, n, dev, antialias=bool(args.antialias), packed=packed_mode)
     gray = args.frame_format == "gray"
     frames, cmds, acts = synth_inputs(torch, dev, n, args.pool, 1234 + rank, gray)
     ingest = pipe.ingest_gray_raw if gray else pipe.ingest
@@ -394,22 +407,29 @@ def main():
         for i in range(args.pool):       # FOV_RES actions carry integer resolutions in [10, 60]
             res = torch.randint(10, 61, (n, 2), device=dev, generator=g).float()
             acts[i] = torch.where(types[i][:, None] == 1, res, acts[i]).contiguous()
-    obs = torch.empty(pipe.obs_shape, dtype=torch.float32, device=dev)
+    obs = None if packed_mode else torch.empty(pipe.obs_shape, dtype=torch.float32, device=dev)
     loc = torch.empty((n, 2), dtype=torch.int32, device=dev)
     res_out = torch.empty((n, 2), dtype=torch.int32, device=dev)
+    packed_buf = offsets = None
+    if packed_mode:      # worst case: every env at the largest window the actions can ask for (60 x 60)
+        packed_buf = torch.empty((n * pipe.frame_stack * 60 * 60,), dtype=torch.float32, device=dev)
+        offsets = torch.empty((n + 1,), dtype=torch.int64, device=dev)
 
     fused = args.kind == "fixed" and args.fused and os.environ.get("AGX_STEP_FUSED") is not None
-    # --split: agx_step_fixed's split step; the sampled steps (every M-th) still run as two stand-alone full-batch
-    # launches carrying their own HIP events - the per-kernel roofline is a solo figure
+    # --split: agx_step_fixed's split step; the sampled steps still run as two stand-alone full-batch launches carrying
+    # their own HIP events - the per-kernel roofline is a solo figure
     split = args.kind == "fixed" and not gray and not fused and (args.split or os.environ.get("AGX_STEP_ENV"))
 
     kernel_events = args.event_mode == "kernel" and not fused
+    issued = {"events": 0}          # HIP events handed to launches / recorded on the stream, counted per phase below
 
     def step(k, e=None):
         """One pass of the hot path over batch k of the pool; `e` = the HIP events of a sampled step: 4 stamped by
         its two launches themselves (kernel mode) or 3 recorded on the stream around them (stream mode)."""
         i = k % args.pool
         sampled = e is not None
+        if e is not None:
+            issued["events"] += len(e)
         if e is not None and kernel_events:
             pipe.profile_next("ingest", e[0], e[1])
             pipe.profile_next("fovea", e[2], e[3])
@@ -425,34 +445,50 @@ def main():
             ingest(frames[i], cmds[i])
             if e is not None:
                 e[1].record()
-            if types is None:
+            if packed_mode:
+                pipe.fovea_packed(acts[i], action_type=types[i], packed=packed_buf, offsets=offsets, loc_out=loc, res_out=res_out)
+            elif types is None:
                 pipe.fovea(acts[i], out=obs, loc_out=loc)
             else:
                 pipe.fovea(acts[i], action_type=types[i], out=obs, loc_out=loc, res_out=res_out)
         if e is not None:
             e[2].record()
 
+    # untimed pre-roll: the device leaves its idle clocks before anything is timed (a 20-step run is 1.3 ms long)
+    for k in range(args.preroll):
+        step(k)
     for k in range(args.warmup):
         step(k)
     K = args.steps
-    use_ev = not args.no_events
-    M = max(1, min(args.event_every, K // 8))        # at least ~8 bracketed steps however short the run
-    ev = {k: [torch.cuda.Event(enable_timing=True) for _ in range(4 if kernel_events else 3)] for k in range(0, K, M)} if use_ev else {}
-    for e in ev.values():          # create the HIP event handles (the fused call records e[1] through the C ABI)
-        for x in e:
-            x.record()
     barrier(dist, local_rank)
     torch.cuda.synchronize(dev)
+    issued["events"] = 0
     t0 = time.perf_counter()
-    # the timed region: exactly K steps; every M-th one has its two launches bracketed by HIP events
-    # recorded on the launch stream (torch's current stream is the stream handed to the C ABI)
+    # the timed region: exactly K plain steps - no event, no profiling hook, nothing but the launches
     for k in range(K):
-        step(k, ev.get(k))
+        step(k)
     torch.cuda.synchronize(dev)
     elapsed = time.perf_counter() - t0
+    events_in_timed_region = issued["events"]
     barrier(dist, local_rank)
     per_rank = all_ranks(elapsed, dist, dev)                 # every rank's own duration of the timed region
     elapsed = max_over_ranks(elapsed, dist, dev)
+
+    # the sampling pass (untimed, rank 0 only; the ranks share nothing): the same step loop continues, and every M-th step's two
+    # launches carry their own start / stop events, on the launch stream (torch's current stream is the one handed to the C ABI)
+    use_ev = not args.no_events and rank == 0
+    M = max(1, args.event_every)
+    S = max(16, args.samples)
+    ev = []
+    if use_ev:
+        ev = [[torch.cuda.Event(enable_timing=True) for _ in range(4 if kernel_events else 3)] for _ in range(S)]
+        for e in ev:                   # create the HIP event handles (the fused call records e[1] through the C ABI)
+            for x in e:
+                x.record()
+        torch.cuda.synchronize(dev)
+        for j in range(S * M):
+            step(K + j, ev[j // M] if j % M == M - 1 else None)
+        torch.cuda.synchronize(dev)
 
     out = None
     if rank == 0:
@@ -461,8 +497,8 @@ def main():
         kernels = {}
         roof = None
         if use_ev:
-            t_ing = sum(e[0].elapsed_time(e[1]) for e in ev.values()) / len(ev) * 1e-3
-            t_fov = sum((e[2].elapsed_time(e[3]) if kernel_events else e[1].elapsed_time(e[2])) for e in ev.values()) / len(ev) * 1e-3
+            t_ing = sum(e[0].elapsed_time(e[1]) for e in ev) / len(ev) * 1e-3
+            t_fov = sum((e[2].elapsed_time(e[3]) if kernel_events else e[1].elapsed_time(e[2])) for e in ev) / len(ev) * 1e-3
             b_ing, b_fov = pipe.algorithmic_bytes("ingest_gray_raw" if gray else "ingest"), pipe.algorithmic_bytes("fovea")
             if args.kind == "flexible":
                 # 4*rh*rw (u8 windows of the 4 stacked frames) + 112,896 B per env, with rh*rw the mean over
@@ -470,6 +506,8 @@ def main():
                 # nominal 30x30 window)
                 win_mean = float((res_out[:, 0].double() * res_out[:, 1].double()).mean().item())
                 b_fov = int(n * pipe.frame_stack * (win_mean + 84 * 84 * 4))
+                if packed_mode:      # ragged raw crops: rh*rw u8 read + rh*rw f32 written per stacked frame
+                    b_fov = int(n * pipe.frame_stack * win_mean * 5)
             if fused:
                 fs = pipe.frame_stack
                 plan = (("k_step_fixed (ingest + fovea of the %d untouched ring slots)" % (fs - 1), b_ing + b_fov * (fs - 1) // fs, t_ing),
@@ -483,9 +521,10 @@ def main():
             roof = {"bound": "hbm", "kernel": dom, "achieved": kernels[dom]["achieved_GBps"], "peak": HBM_PEAK_GBS,
                     "unit": "GB/s", "frac": kernels[dom]["frac"], "traffic": None,
                     "avg_launch_us": kernels[dom]["avg_us"], "algorithmic_bytes_per_launch": kernels[dom]["algorithmic_bytes"],
-                    "launches_timed": len(ev), "timing": (f"HIP start/stop events stamped by the launch itself (hipExtLaunchKernelGGL) on every {M}th step of the "
-                               "timed region, on the launch stream" if kernel_events else
-                               f"HIP events recorded on the launch stream around every {M}th step of the timed region")}
+                    "launches_timed": len(ev), "timing": (f"HIP start/stop events stamped by the launch itself (hipExtLaunchKernelGGL), on the launch stream, on every "
+                               f"{M}th step of a {S * M}-step sampling pass that continues the step loop right after the timed region "
+                               "(the timed region itself carries no events)" if kernel_events else
+                               f"HIP events recorded on the launch stream around every {M}th step of a {S * M}-step sampling pass after the timed region")}
             tr, why = pmc_traffic(dom, n, args.kind)
             if tr is not None:
                 roof["traffic"] = tr["traffic"]
@@ -496,15 +535,17 @@ def main():
         out = {
             "metric": "env steps/sec at N=1024 AtariFixedFovealEnv; 1/2/4/8-GPU scaling",
             "value": total_envs * K / elapsed, "unit": "env steps/s", "n_gpus": world, "steps": K, "warmup": args.warmup,
+            "preroll": args.preroll, "events_in_timed_region": events_in_timed_region,
             "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "u8 ingest / f32 resize", "data": "synthetic",
             "config": {"workload": f"{n}x AtariFixedFovealEnv-shaped envs per GPU (kind={args.kind}), 84x84 obs, 30x30 fov, "
-                                   "frame_stack=4, action_repeat=4, resize_to_full, absolute sensory actions; "
+                                   "frame_stack=4, action_repeat=4, " + ("ragged raw crops packed (agx_fovea_flexible_packed)" if packed_mode else "resize_to_full")
+                                   + (f", antialias={args.antialias}" if args.kind != "fixed" else "") + ", absolute sensory actions; "
                                    + ("device-resident synthetic RGB frames (BASELINE.json configs[1])" if not gray else
                                       "device-resident synthetic GRAY screens (getScreenGrayscale format) - NOT the metric's workload"),
                        "envs_per_gpu": n, "total_envs": total_envs, "input_pool": args.pool,
                        "step_form": ("agx_step_fixed split step (env-range parts on internal streams, AGX_STEP_SPLIT=%s); every %dth "
-                                     "step as two stand-alone full-batch launches carrying the roofline's HIP events"
+                                     "step of the sampling pass as two stand-alone full-batch launches carrying the roofline's HIP events"
                                      % (os.environ.get("AGX_STEP_SPLIT", "default 2"), M)) if split else "two stand-alone launches per step",
                        "parallelism": f"env-shard x{world}, no collective"},
             "roofline": roof, "kernels": kernels, "build": _build_info(),

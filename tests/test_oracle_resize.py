@@ -48,6 +48,36 @@ def test_luminance_known_answers():
     assert np.array_equal(O.ale_luminance(rgb), want)
 
 
+def test_band12_luminance_arithmetic():
+    """The integer luminance of the band12 ingest kernel (agx_k1_ingest.h: lum_x), restated in NumPy, against the oracle
+    for ALL 2^24 colours: T8 = 8 (2989 r + 5870 g + 1140 b + 5000) from two 8-bit-weight dot products, X = (T8 *
+    ceil(2^45 / 10^4)) >> 32; byte 2 of X is the gray value unless the low 16 bits are 0 (an exact .5 tie, re-done in
+    double by the kernel), byte 3 is 0."""
+    M = np.uint64(3518437209)
+    assert int(M) == -(-(1 << 45) // 10000)
+    g, b = np.meshgrid(np.arange(256, dtype=np.uint64), np.arange(256, dtype=np.uint64), indexing="ij")
+    rgb = np.empty((256, 256, 3), np.uint8)
+    rgb[..., 1], rgb[..., 2] = g, b
+    n_ties = n_fix = 0
+    for r in range(256):
+        rr = np.uint64(r)
+        hi = 93 * rr + 183 * g + 35 * b + 156
+        t8 = (hi << np.uint64(8)) + 64 + 104 * rr + 112 * g + 160 * b
+        t = 2989 * rr + 5870 * g + 1140 * b + 5000
+        assert np.array_equal(t8, 8 * t) and int(t8.max()) < 1 << 32
+        x = (t8 * M) >> np.uint64(32)
+        assert int((x >> np.uint64(24)).max()) == 0
+        q = ((x >> np.uint64(16)) & np.uint64(0xFF)).astype(np.uint8)
+        tie = (x & np.uint64(0xFFFF)) == 0
+        assert np.array_equal(tie, (t % 10000) == 0)
+        rgb[..., 0] = r
+        want = O.ale_luminance(rgb)
+        assert np.array_equal(q[~tie], want[~tie])
+        n_ties += int(tie.sum())
+        n_fix += int((q[tie] != want[tie]).sum())
+    assert n_ties == 1703 and n_fix == 292      # ties the kernel replays in double / of which the double lands below .5
+
+
 def test_cv_resize_constant_and_range():
     for v in (0, 1, 127, 128, 254, 255):
         img = np.full((210, 160), v, np.uint8)

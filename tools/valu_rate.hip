@@ -29,6 +29,16 @@ __global__ __launch_bounds__(256) void k(unsigned *out, unsigned long long *cyc,
             if (OP == 10) asm volatile("v_lshrrev_b32 %0, 5, %0" : "+v"(a[i]));
             if (OP == 11) asm volatile("v_mul_lo_u32 %0, %0, %1" : "+v"(a[i]) : "v"(c));
             if (OP == 12) asm volatile("v_cvt_f32_ubyte1 %0, %0" : "+v"(a[i]));
+            if (OP == 13) asm volatile("v_mul_hi_u32 %0, %0, %1" : "+v"(a[i]) : "v"(c));
+            if (OP == 14) asm volatile("v_min3_u16 %0, %0, %1, %2" : "+v"(a[i]) : "v"(b), "v"(c));
+            if (OP == 15) asm volatile("v_pk_min_u16 %0, %0, %1" : "+v"(a[i]) : "v"(b));
+            if (OP == 16) asm volatile("v_bfe_u32 %0, %0, 13, 8" : "+v"(a[i]));
+            if (OP == 17) asm volatile("v_and_or_b32 %0, %0, %1, %2" : "+v"(a[i]) : "v"(b), "v"(c));
+            if (OP == 18) asm volatile("v_mad_u32_u24 %0, %0, %1, %2" : "+v"(a[i]) : "v"(b), "v"(c));
+            if (OP == 19) asm volatile("v_lshl_or_b32 %0, %0, 8, %1" : "+v"(a[i]) : "v"(b));
+            if (OP == 20) asm volatile("v_mad_u64_u32 %0, vcc, %1, %2, %0" : "+v"(*(unsigned long long*)&a[i & ~1]) : "v"(b), "v"(c) : "vcc");
+            if (OP == 21) asm volatile("v_and_b32 %0, %0, %1" : "+v"(a[i]) : "v"(c));
+            if (OP == 22) asm volatile("v_max_u32 %0, %0, %1" : "+v"(a[i]) : "v"(c));
         }
     }
     const unsigned long long t1 = __builtin_amdgcn_s_memtime();
@@ -76,5 +86,15 @@ int main() {
     run<9>("v_min3_u32", out, cyc, blocks);
     run<10>("v_lshrrev_b32", out, cyc, blocks);
     run<12>("v_cvt_f32_ubyte1", out, cyc, blocks);
+    run<13>("v_mul_hi_u32", out, cyc, blocks);
+    run<14>("v_min3_u16", out, cyc, blocks);
+    run<15>("v_pk_min_u16", out, cyc, blocks);
+    run<16>("v_bfe_u32", out, cyc, blocks);
+    run<17>("v_and_or_b32", out, cyc, blocks);
+    run<18>("v_mad_u32_u24", out, cyc, blocks);
+    run<19>("v_lshl_or_b32", out, cyc, blocks);
+    run<20>("v_mad_u64_u32", out, cyc, blocks);
+    run<21>("v_and_b32", out, cyc, blocks);
+    run<22>("v_max_u32", out, cyc, blocks);
     return 0;
 }
