@@ -167,14 +167,15 @@ class DMCHostRunner:
         reward = np.sign(raw) if self.clip_reward else raw.copy()                            # dmc_env.py:232
         return reward, done, np.full(self.num_envs, 1, np.uint8), raw
 
-    def reset(self, idx: Optional[Sequence[int]] = None, out: Optional[np.ndarray] = None) -> np.ndarray:
+    def reset(self, idx: Optional[Sequence[int]] = None, out: Optional[np.ndarray] = None, packed: bool = False) -> np.ndarray:
         idx = list(range(self.num_envs)) if idx is None else [int(i) for i in idx]
         buf = self.frames if out is None else out
         cmd = np.full(self.num_envs, nat.CMD_SKIP, np.uint8)
+        row_of = {i: j for j, i in enumerate(idx)} if packed else None     # packed: the j-th reset env's render in row j
 
         def one(i):
             ts = self.envs[i].reset()                                                         # dmc_env.py:204
-            self._render(i, buf[i])
+            self._render(i, buf[i if row_of is None else row_of[i]])
             self._after(i, ts)
             cmd[i] = nat.CMD_CLEAR | 1                                                        # _reset_buffer + one append
 
@@ -207,6 +208,7 @@ class DMCVecEnv(AtariVecEnv):
         self._d_cmd = torch.empty((self.num_envs,), dtype=torch.uint8, device=self.device)
         self._ev_copy = torch.cuda.Event()
         self._ev_rcopy = torch.cuda.Event()
+        self._alloc_reset_buffers()
         self.runner = DMCHostRunner(args, self.num_envs, self._h_frames.numpy(), workers=getattr(args, "num_workers", None),
                                     env_offset=env_offset)
         mode = getattr(args, "gray_mode", "cv15")
@@ -220,15 +222,11 @@ class DMCVecEnv(AtariVecEnv):
     def _ingest(self):
         self.pipe.ingest_rgb(self._d_frames, self._d_cmd, self._gray_mode)
 
-    def _upload_reset(self, cmd, idx):
-        self._h_rcmd.numpy()[:] = cmd
-        self._d_cmd.copy_(self._h_rcmd, non_blocking=True)
-        if idx is None:
-            self._d_frames.copy_(self._h_rframes, non_blocking=True)
-        else:
-            for i in idx:
-                self._d_frames[int(i)].copy_(self._h_rframes[int(i)], non_blocking=True)
-        self._ev_rcopy.record(torch.cuda.current_stream(self.device))
+    def _h_reset_rows(self):
+        return self._h_rframes
+
+    def _d_reset_target(self):
+        return self._d_frames
 
     def _extra_info(self, info):                                                               # dmc_env.py:189-192
         info["internal_state"] = np.stack([np.asarray(s) for s in self.runner.internal_state])

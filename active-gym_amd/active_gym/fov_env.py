@@ -9,6 +9,8 @@ switch the one-env device core underneath to their kernel kind, so the crop /
 mask / resize / peripheral arithmetic runs in libagx.so."""
 from __future__ import annotations
 
+import copy
+
 from enum import IntEnum
 
 import numpy as np
@@ -195,7 +197,10 @@ class FlexibleFovealEnv(FixedFovealEnv):
 
     def __init__(self, env, args):
         if not (getattr(args, "mask_out", False) or getattr(args, "resize_to_full", False)):
-            args.ragged_obs = "packed"                           # single env, raw crops: return the ragged view itself
+            # single env, raw crops: return the ragged view itself.  The flag goes on a COPY: the caller's args object may
+            # build other envs later (an AtariVecEnv of kind "flexible" must keep returning the padded batch)
+            args = copy.copy(args)
+            args.ragged_obs = "packed"
         super().__init__(env, args)
         self.action_space["sensory_action_type"] = Discrete(len(FlexibleFovealEnvActionType))
         self.fov_init_res = tuple(args.fov_size)

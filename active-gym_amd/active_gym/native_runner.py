@@ -38,6 +38,7 @@ SIGNATURES = {
     "agxr_step_begin": (C.c_int, [_P, _P, _P, _P, _P, _P, _P, C.c_int32]),
     "agxr_step_wait": (C.c_int, [_P, C.c_int32]),
     "agxr_reset": (C.c_int, [_P, _P, C.c_int32, _P, _P, C.c_int64, _P]),
+    "agxr_reset_packed": (C.c_int, [_P, _P, C.c_int32, _P, _P, C.c_int64, _P]),
     "agxr_get_state": (C.c_int, [_P, _P, _P]),
     "agxr_render": (C.c_int, [_P, C.c_int32, _P]),
 }
@@ -181,7 +182,9 @@ class NativeHostRunner:
         self._check(self._lib.agxr_step_wait(self._h, -1))
         return self._rew.copy(), self._done.astype(bool), self._cmd.copy(), self._raw.copy()
 
-    def reset(self, idx: Optional[Sequence[int]] = None, out: Optional[np.ndarray] = None) -> np.ndarray:
+    def reset(self, idx: Optional[Sequence[int]] = None, out: Optional[np.ndarray] = None, packed: bool = False) -> np.ndarray:
+        """Reset the envs in `idx` (all by default); env i's reset screen goes to ``out[i, 0]``, or - ``packed`` - the j-th
+        reset env's to ``out[j, 0]`` (the vector env uploads the reset screens of one step as ONE contiguous copy)."""
         idx = np.arange(self.num_envs, dtype=np.int32) if idx is None else np.asarray(list(idx), dtype=np.int32)
         lt = self.life_termination
         # no-op counts are drawn here, in env order, only for full resets - like the Python runner
@@ -190,8 +193,8 @@ class NativeHostRunner:
         buf = self.frames if out is None else out
         assert buf.dtype == np.uint8 and buf.flags.c_contiguous and buf.shape[0] == self.num_envs
         stride = buf.strides[0]
-        self._check(self._lib.agxr_reset(self._h, idx.ctypes.data, len(idx), noops.ctypes.data, buf.ctypes.data, stride,
-                                         self._cmd.ctypes.data))
+        fn = self._lib.agxr_reset_packed if packed else self._lib.agxr_reset
+        self._check(fn(self._h, idx.ctypes.data, len(idx), noops.ctypes.data, buf.ctypes.data, stride, self._cmd.ctypes.data))
         return self._cmd.copy()
 
     def render(self, i=0, size=(256, 256)):

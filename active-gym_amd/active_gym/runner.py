@@ -101,9 +101,9 @@ class AtariHostRunner:
     def eval(self):
         self.training = False
 
-    def _grab(self, i, slot, buf=None):
+    def _grab(self, i, slot, buf=None, row=None):
         e = self.emulators[i]
-        dst = (self.frames if buf is None else buf)[i, slot]
+        dst = (self.frames if buf is None else buf)[i if row is None else row, slot]
         if self.gray:
             np.copyto(dst, np.asarray(e.getScreenGrayscale()).reshape(RAW_H, RAW_W))
         else:
@@ -161,11 +161,12 @@ class AtariHostRunner:
         return ret, done, cmd, raw
 
     # ------------------------------------------------------------------ reset  (atari_env.py:84-117)
-    def reset(self, idx: Optional[Sequence[int]] = None, out: Optional[np.ndarray] = None) -> np.ndarray:
+    def reset(self, idx: Optional[Sequence[int]] = None, out: Optional[np.ndarray] = None, packed: bool = False) -> np.ndarray:
         """Reset the envs in `idx` (all by default).  The single reset screen of env i goes to
-        ``out[i, 0]`` (default: the step staging buffer)."""
+        ``out[i, 0]`` (default: the step staging buffer), or - ``packed`` - the j-th reset env's to ``out[j, 0]``."""
         n = self.num_envs
         idx = list(range(n)) if idx is None else [int(i) for i in idx]
+        row_of = {i: j for j, i in enumerate(idx)} if packed else None
         cmd = np.full(n, nat.CMD_SKIP, np.uint8)
         # no-op counts are drawn on the calling thread, in env order, from the global RNG
         noops = {i: (0 if self.life_termination[i] else self._draw_noops(i)) for i in idx}
@@ -190,7 +191,7 @@ class AtariHostRunner:
                     e.act(2)
                 if e.game_over():
                     e.reset_game()
-            self._grab(i, 0, out)
+            self._grab(i, 0, out, None if row_of is None else row_of[i])
             self.lives[i] = e.lives()
             cmd[i] = 1 | clear
 

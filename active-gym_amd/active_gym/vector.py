@@ -195,6 +195,7 @@ class AtariVecEnv:
         # screens whose asynchronous H2D copy may still be in flight
         self._h_rframes = torch.empty((self.num_envs, 1, nat.RAW_H, nat.RAW_W) + px, dtype=torch.uint8, pin_memory=True)
         self._h_rcmd = torch.empty((self.num_envs,), dtype=torch.uint8, pin_memory=True)
+        self._alloc_reset_buffers()
         self._ev_copy = self._stage[0]["ev"]
         self._ev_rcopy = torch.cuda.Event()
         self._h_cmd = self._stage[0]["cmd"]
@@ -212,6 +213,24 @@ class AtariVecEnv:
             self.runner = AtariHostRunner(args, self.num_envs, frames=self._h_frames.numpy(),
                                           workers=getattr(args, "num_workers", None), noop_fn=noop_fn,
                                           env_offset=env_offset, noop_per_env=self._noop_per_env)
+
+    def _alloc_reset_buffers(self):
+        # resets of a subset of the envs (the autoreset inside step()): the runner writes their screens PACKED into the first
+        # K rows of _h_rframes; one contiguous H2D copy into _d_rframes, one index_copy_ into slot 0 of the step screens.  The
+        # env indices and the done mask travel through pinned buffers too (a pageable .to(device) is a synchronous copy).
+        self._d_rframes = None                  # allocated at the first partial reset
+        self._h_ridx = torch.empty((self.num_envs,), dtype=torch.int64, pin_memory=True)
+        self._d_ridx = torch.empty((self.num_envs,), dtype=torch.int64, device=self.device)
+        self._h_rmask = torch.empty((self.num_envs,), dtype=torch.uint8, pin_memory=True)
+        self._d_rmask = torch.empty((self.num_envs,), dtype=torch.uint8, device=self.device)
+
+    def _h_reset_rows(self):
+        """Pinned reset screens, one row per env (Atari: slot 0 of a [N, 1, ...] buffer)."""
+        return self._h_rframes[:, 0]
+
+    def _d_reset_target(self):
+        """Where a reset screen lands on the device: slot 0 of the env's step screens."""
+        return self._d_frames[:, 0]
 
     # ------------------------------------------------------------------ plumbing
     def close(self):
@@ -239,15 +258,35 @@ class AtariVecEnv:
         self._d_frames.copy_(self._h_frames, non_blocking=True)
         self._ev_copy.record(torch.cuda.current_stream(self.device))
 
-    def _upload_reset(self, cmd: np.ndarray, idx):
-        """H2D of the reset screens of the envs in `idx` (slot 0 only) and their command bytes."""
+    def _reset_subset(self, idx):
+        """runner.reset of the envs in `idx` + H2D of their screens and command bytes: the runner packs the K reset screens into
+        the first K rows of the pinned reset buffer, which cross PCIe as ONE copy and land in slot 0 of their envs' step screens
+        through one index_copy_ (round 2: one copy per done env).  Returns the done mask as a device tensor."""
+        idx = np.asarray(idx, dtype=np.int64)
+        k = len(idx)
+        self._ev_rcopy.synchronize()            # the previous partial reset has left the pinned reset buffers
+        cmd = self.runner.reset(idx, out=self._h_rframes.numpy(), packed=True)
+        self._h_rcmd.numpy()[:] = cmd
+        self._h_ridx.numpy()[:k] = idx
+        m = self._h_rmask.numpy()
+        m[:] = 0
+        m[idx] = 1
+        rows = self._h_reset_rows()
+        if self._d_rframes is None:
+            self._d_rframes = torch.empty(rows.shape, dtype=torch.uint8, device=self.device)
+        self._d_cmd.copy_(self._h_rcmd, non_blocking=True)
+        self._d_ridx[:k].copy_(self._h_ridx[:k], non_blocking=True)
+        self._d_rmask.copy_(self._h_rmask, non_blocking=True)
+        self._d_rframes[:k].copy_(rows[:k], non_blocking=True)
+        self._d_reset_target().index_copy_(0, self._d_ridx[:k], self._d_rframes[:k])
+        self._ev_rcopy.record(torch.cuda.current_stream(self.device))
+        return self._d_rmask
+
+    def _upload_reset_all(self, cmd: np.ndarray):
+        """H2D of every env's reset screen (slot 0 only: one strided copy) and the command bytes."""
         self._h_rcmd.numpy()[:] = cmd
         self._d_cmd.copy_(self._h_rcmd, non_blocking=True)
-        if idx is None:                     # every env: one strided copy
-            self._d_frames[:, 0].copy_(self._h_rframes[:, 0], non_blocking=True)
-        else:
-            for i in idx:
-                self._d_frames[int(i), 0].copy_(self._h_rframes[int(i), 0], non_blocking=True)
+        self._d_reset_target().copy_(self._h_reset_rows(), non_blocking=True)
         self._ev_rcopy.record(torch.cuda.current_stream(self.device))
 
     def _as_device_action(self, a, cols):
@@ -342,12 +381,15 @@ class AtariVecEnv:
         self._ev_copy.synchronize()
         self._ev_rcopy.synchronize()
         cmd = self.runner.reset(out=self._h_rframes.numpy())
-        self._upload_reset(cmd, None)
+        self._upload_reset_all(cmd)
         self._ingest()
         self.cumulative_reward[:] = 0
         self.ep_len[:] = 0
         if self.kind != "base":
             self.pipe.fovea_reset()
+        # a fresh output buffer: the observation a caller still holds from the previous step() (valid until the step after
+        # next) must not be overwritten by the reset observation
+        self._next_obs_buffer()
         obs = self._observe()
         self._was_reset = True
         return self._ret_obs(obs), self._with_masks(self._info(np.zeros(self.num_envs)), self.num_envs)
@@ -398,20 +440,20 @@ class AtariVecEnv:
                 cur = self._ret_obs(obs)
                 fo = [cur[i].copy() if isinstance(cur[i], np.ndarray) else cur[i].clone() for i in idx]
             else:
-                fo = self._out(obs[torch.from_numpy(idx).to(self.device)].clone())
+                self._ev_rcopy.synchronize()
+                self._h_ridx.numpy()[:len(idx)] = idx
+                self._d_ridx[:len(idx)].copy_(self._h_ridx[:len(idx)], non_blocking=True)
+                fo = self._out(obs.index_select(0, self._d_ridx[:len(idx)]))
             for k, i in enumerate(idx):
                 final_obs[i] = fo[k]
                 final_info[i] = {key: (val[i].copy() if isinstance(val[i], np.ndarray) else
                                        (val[i].clone() if isinstance(val[i], torch.Tensor) else val[i]))
                                  for key, val in info.items()}
             # env.reset() of the done envs inside the same step (SyncVectorEnv, gymnasium<1.0)
-            self._ev_rcopy.synchronize()
-            cmd2 = self.runner.reset(idx, out=self._h_rframes.numpy())
-            self._upload_reset(cmd2, idx)
+            mask = self._reset_subset(idx)
             self._ingest()
             self.cumulative_reward[idx] = 0
             self.ep_len[idx] = 0
-            mask = torch.from_numpy(done.astype(np.uint8)).to(self.device)
             if self.kind == "base":
                 self._observe()
             else:
@@ -433,15 +475,14 @@ class AtariVecEnv:
         """Reset only the envs in `idx` (what a caller without autoreset does after `done`)."""
         idx = [int(i) for i in idx]
         n = self.num_envs
-        self._ev_rcopy.synchronize()
-        cmd = self.runner.reset(idx, out=self._h_rframes.numpy())
-        self._upload_reset(cmd, idx)
+        mask = self._reset_subset(idx)
         self._ingest()
         self.cumulative_reward[idx] = 0
         self.ep_len[idx] = 0
-        m = np.zeros(n, np.uint8)
-        m[idx] = 1
-        mask = torch.from_numpy(m).to(self.device)
+        # a fresh output buffer, as in reset(): the terminal observation the caller holds from step() stays untouched
+        self._next_obs_buffer()
+        if self.kind != "base" and len(self._obs_bufs) > 1:
+            self._obs.copy_(self._obs_bufs[self._obs_i ^ 1])        # masked observe: the other envs keep their observation
         if self.kind == "base":
             obs = self._observe()
         else:

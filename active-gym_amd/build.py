@@ -16,8 +16,11 @@ REPO = os.path.dirname(HERE)
 SRC = os.path.join(HERE, "csrc", "agx_api.hip")
 DEPS = [SRC] + sorted(os.path.join(HERE, "csrc", f) for f in os.listdir(os.path.join(HERE, "csrc")) if f.endswith(".h")) + \
        [os.path.join(REPO, "include", "agx.h")]
+# the measured dead ends (csrc/experiments/): compiled only into libagx_exp.so, for tools/ and tests/test_gpu_variants.py
+EXP_DEPS = sorted(os.path.join(HERE, "csrc", "experiments", f) for f in os.listdir(os.path.join(HERE, "csrc", "experiments")))
 OUT_DIR = os.path.join(HERE, "lib")
 OUT = os.path.join(OUT_DIR, "libagx.so")
+EXP_OUT = os.path.join(OUT_DIR, "libagx_exp.so")
 
 
 def hipcc():
@@ -37,23 +40,30 @@ def source_hash():
     return h.hexdigest()[:12]
 
 
-def up_to_date():
-    return os.path.exists(OUT) and all(os.path.getmtime(OUT) >= os.path.getmtime(d) for d in DEPS)
+def up_to_date(out=OUT, deps=None):
+    deps = DEPS if deps is None else deps
+    return os.path.exists(out) and all(os.path.getmtime(out) >= os.path.getmtime(d) for d in deps)
 
 
-def build(force=False, verbose=False, extra=()):
-    if not force and up_to_date():
-        return OUT
+def build(force=False, verbose=False, extra=(), out=OUT, deps=None):
+    if not force and up_to_date(out, deps):
+        return out
     os.makedirs(OUT_DIR, exist_ok=True)
     cmd = [hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared",
            "-fvisibility=hidden", "-Wall", "-Wno-unused-function",
            "-I", os.path.join(REPO, "include"), "-I", os.path.join(HERE, "csrc"),
-           "-DAGX_BUILD", f'-DAGX_SRC_HASH="{source_hash()}"', *extra, SRC, "-o", OUT + ".tmp"]
+           "-DAGX_BUILD", f'-DAGX_SRC_HASH="{source_hash()}"', *extra, SRC, "-o", out + ".tmp"]
     if verbose:
         print(" ".join(cmd))
     subprocess.run(cmd, check=True)
-    os.replace(OUT + ".tmp", OUT)
-    return OUT
+    os.replace(out + ".tmp", out)
+    return out
+
+
+def build_experiments(force=False, verbose=False):
+    """libagx_exp.so = libagx.so + the kernel forms under csrc/experiments/ and their environment knobs (-DAGX_EXPERIMENTS).
+    Never loaded by the product: tools/ and tests/test_gpu_variants.py select it through AGX_LIB."""
+    return build(force, verbose, ("-DAGX_EXPERIMENTS",), EXP_OUT, DEPS + EXP_DEPS)
 
 
 RUNNER_SRC = os.path.join(HERE, "csrc", "agx_runner.cpp")
@@ -77,6 +87,8 @@ def build_runner(force=False, verbose=False):
 
 
 if __name__ == "__main__":
-    extra = [a for a in sys.argv[1:] if a.startswith("-") and a not in ("-f", "-v")]
+    extra = [a for a in sys.argv[1:] if a.startswith("-") and a not in ("-f", "-v", "--experiments")]
     print(build(force="-f" in sys.argv, verbose=True, extra=extra))
     print(build_runner(force="-f" in sys.argv, verbose=True))
+    if "--experiments" in sys.argv:
+        print(build_experiments(force="-f" in sys.argv, verbose=True))

@@ -16,6 +16,7 @@
 #include "agx.h"
 #include "agx_kernels.h"
 #include "agx_host_tables.h"
+#include "agx_device_guard.h"
 
 using namespace agx;
 
@@ -56,32 +57,36 @@ struct agx_ctx {
     int p3_mt = 0;
     size_t p3_lds = 0;
     std::vector<void *> owned;    // further device allocations freed by agx_destroy
+#ifdef AGX_EXPERIMENTS
     // split step (agx_step_fixed): env-range parts 1.. run on these internal streams, forked from / joined to the caller's
     hipStream_t aux[3] = {nullptr, nullptr, nullptr};
     hipEvent_t ev_fork = nullptr, ev_join[3] = {nullptr, nullptr, nullptr};
+#endif
     int band_rows = 0;
     int ingest_t = 256;
     int rows_touched = 0;
     int y_affine = 0, y_mul = 0, y_add = 0, y_shift = 0;   // see IngestParams
     int init_r = 0, init_c = 0;
     hipEvent_t prof[2][2] = {{nullptr, nullptr}, {nullptr, nullptr}};   // agx_profile_next: [ingest | fovea][start | stop]
-    // Tuning / testing knobs, read from the environment ONCE PER CONTEXT in agx_create (so one process can hold
-    // contexts of several variants and compare them: tests/test_gpu_parity.py::test_kernel_variants_bit_identical).
-    // Every variant is bit-identical to the default; the defaults are the measured-fastest forms.
+    // Testing knobs, read from the environment ONCE PER CONTEXT in agx_create (so one process can hold contexts of
+    // several forms and compare them).  The shipped library has only the four that select a FALLBACK kernel, i.e. the
+    // kernel other geometries get anyway (tests/test_gpu_parity.py::test_generic_fallback_kernel_matches_tuned); the rest
+    // exist in the experiments build (-DAGX_EXPERIMENTS, experiments/agx_experiments.h) only.
     struct Tune {
+        int generic = 0;         // AGX_FOVEA_GENERIC     K3 / K4 through the generic fallback kernel
+        int no_full = 0;         // AGX_INGEST_NO_FULL    general k_ingest<256> even where k_ingest_full12 applies
+        int flex_v2 = 0;         // AGX_FLEX_V2           K4 through k_fovea_flexible2 (pass-by-pass form)
+        int per_v2 = 0;          // AGX_PER_V2            K3 through k_fovea_peripheral2
+        // ---- experiments build only (always 0 in libagx.so)
         int ingest_t = 0;        // AGX_INGEST_T          128 | 256 threads per ingest workgroup
         int band_rows = 0;       // AGX_INGEST_BAND_ROWS  output rows per ingest workgroup (<= the default)
         int pipe_parts = 0;      // AGX_INGEST_PIPE       k_ingest_pipe with this many workgroups per env
         int wave = 0;            // AGX_INGEST_WAVE       wave-private (barrier-free) ingest
         int pair = 0;            // AGX_FOVEA_PAIR        two ring slots per K2 workgroup
         int fused = 0;           // AGX_STEP_FUSED        agx_step_fixed as one heterogeneous launch + tail
-        int generic = 0;         // AGX_FOVEA_GENERIC     K3 / K4 through the generic fallback kernel
-        int no_full = 0;         // AGX_INGEST_NO_FULL    general k_ingest<256> even where k_ingest_full12 applies
-        int flex_v2 = 0;         // AGX_FLEX_V2           K4 resize_to_full through k_fovea_flexible2 (pass-by-pass form)
-        int per_v2 = 0;          // AGX_PER_V2            K3 through k_fovea_peripheral2
-        int pair12 = 0;          // AGX_INGEST_PAIR12     k_ingest_pair12: two envs' bands per workgroup, second env's loads under the first's tail
+        int pair12 = 0;          // AGX_INGEST_PAIR12     k_ingest_pair12: two envs' bands per workgroup
         int step_env = 0;        // AGX_STEP_ENV          agx_step_fixed as ONE launch, one workgroup per env (k_step_env)
-        int split = 0;           // AGX_STEP_SPLIT        env-range parts of agx_step_fixed on internal streams (default 1 = one launch pair)
+        int split = 0;           // AGX_STEP_SPLIT        env-range parts of agx_step_fixed on internal streams
         int aux_prio = 0;        // AGX_STEP_AUX_PRIO     -1 | 0 | 1: priority of the internal streams relative to normal
     } tune;
     std::string err;
@@ -130,17 +135,11 @@ int fail(agx_ctx *ctx, int code, const char *fmt, ...) {
         if (e_ != hipSuccess) return fail((ctx), AGX_E_HIP, "%s: %s", #expr, hipGetErrorString(e_)); \
     } while (0)
 
-struct DeviceGuard {
-    int prev = -1;
-    bool ok = true;
-    explicit DeviceGuard(int dev) {
-        if (hipGetDevice(&prev) != hipSuccess) prev = -1;
-        if (prev != dev) ok = hipSetDevice(dev) == hipSuccess;
-    }
-    ~DeviceGuard() {
-        if (prev >= 0) (void)hipSetDevice(prev);
-    }
+struct HipDeviceApi {
+    static int get(int *dev) { return hipGetDevice(dev) == hipSuccess ? 0 : 1; }
+    static int set(int dev) { return hipSetDevice(dev) == hipSuccess ? 0 : 1; }
 };
+using DeviceGuard = agx::DeviceGuardT<HipDeviceApi>;      // agx_device_guard.h (unit-tested with a mocked runtime)
 
 inline hipStream_t S(void *s) { return static_cast<hipStream_t>(s); }
 
@@ -296,12 +295,18 @@ int upload_owned(agx_ctx *ctx, const T **dptr, const std::vector<T> &h) {
 bool has_fovea(const agx_config &c) { return c.kind != AGX_KIND_BASE; }
 
 size_t fixed_lds(const agx_config &c) {
-    // lut[256] f32 | raw frame u8 (16-B padded) | ytab[oh] | H[fh][ow]
-    const size_t raw = ((size_t)c.obs_h * c.obs_w + 15) & ~(size_t)15;
-    size_t b = 1024 + raw;
+    // window image u8 [fh][4 * ((fw + 6) / 4)] (16-B padded) | ytab[oh] | H[fh][ow]   (the carve of fovea_fixed_body)
+    const size_t raw = ((size_t)c.fov_h * 4 * ((c.fov_w + 6) / 4) + 15) & ~(size_t)15;
+    size_t b = raw;
     if (c.out_mode == AGX_OUT_RESIZE) b += (size_t)c.obs_h * sizeof(Tap) + (size_t)c.fov_h * c.obs_w * sizeof(float);
     return b;
 }
+#ifdef AGX_EXPERIMENTS
+size_t fixed2_lds(const agx_config &c) {     // k_fovea_fixed2: lut[256] f32 | raw frame u8 (16-B padded) | ytab[oh] | H[fh][ow]
+    const size_t raw = ((size_t)c.obs_h * c.obs_w + 15) & ~(size_t)15;
+    return 1024 + raw + (size_t)c.obs_h * sizeof(Tap) + (size_t)c.fov_h * c.obs_w * sizeof(float);
+}
+#endif
 
 // second LDS buffer of the generic kernels, in floats: flexible ping-pongs two full frames,
 // peripheral keeps A[oh][pw] | B[ph][pw] | C[ph][ow] there
@@ -351,11 +356,13 @@ int agx_destroy(agx_ctx *ctx) {
         if (p) (void)hipFree(p);
     for (void *p : ctx->owned)
         if (p) (void)hipFree(p);
+#ifdef AGX_EXPERIMENTS
     for (hipStream_t st : ctx->aux)
         if (st) (void)hipStreamDestroy(st);
     if (ctx->ev_fork) (void)hipEventDestroy(ctx->ev_fork);
     for (hipEvent_t e : ctx->ev_join)
         if (e) (void)hipEventDestroy(e);
+#endif
     delete ctx;
     return AGX_OK;
 }
@@ -405,20 +412,22 @@ int agx_create(const agx_config *cfg, agx_ctx **out) {
     agx_ctx *ctx = new (std::nothrow) agx_ctx;
     if (!ctx) return fail(nullptr, AGX_E_NOMEM, "out of host memory");
     ctx->cfg = c;
+    ctx->tune.generic = env_int("AGX_FOVEA_GENERIC");
+    ctx->tune.no_full = env_int("AGX_INGEST_NO_FULL");
+    ctx->tune.flex_v2 = env_int("AGX_FLEX_V2");
+    ctx->tune.per_v2 = env_int("AGX_PER_V2");
+#ifdef AGX_EXPERIMENTS
     ctx->tune.ingest_t = env_int("AGX_INGEST_T");
     ctx->tune.band_rows = env_int("AGX_INGEST_BAND_ROWS");
     ctx->tune.pipe_parts = env_int("AGX_INGEST_PIPE");
     ctx->tune.wave = env_int("AGX_INGEST_WAVE");
     ctx->tune.pair = env_int("AGX_FOVEA_PAIR");
     ctx->tune.fused = env_int("AGX_STEP_FUSED");
-    ctx->tune.generic = env_int("AGX_FOVEA_GENERIC");
-    ctx->tune.no_full = env_int("AGX_INGEST_NO_FULL");
-    ctx->tune.flex_v2 = env_int("AGX_FLEX_V2");
-    ctx->tune.per_v2 = env_int("AGX_PER_V2");
     ctx->tune.pair12 = env_int("AGX_INGEST_PAIR12");
     ctx->tune.step_env = env_int("AGX_STEP_ENV");
     ctx->tune.split = env_int("AGX_STEP_SPLIT");
     ctx->tune.aux_prio = env_int("AGX_STEP_AUX_PRIO", 0);
+#endif
     DeviceGuard g(c.device);
     int rc = AGX_OK;
     auto bail = [&](int code) {
@@ -713,6 +722,8 @@ int agx_ingest(agx_ctx *ctx, const uint8_t *d_frames, const uint8_t *d_cmd, void
     const IngestParams p = ingest_params(ctx, d_frames, d_cmd);
     const int bands = p.nbands;
     const size_t lds = ingest_lds(ctx);
+#ifdef AGX_EXPERIMENTS
+    bool launched = true;
     const int pipe_parts = ctx->tune.pipe_parts;
     // wave-private form: needs the affine row form, band_rows = 4 * RPW with RPW * ow/4 <= 64 lanes and
     // 2 frames * RPW rows * 40 pieces <= 240 (RPW <= 3)
@@ -736,10 +747,17 @@ int agx_ingest(agx_ctx *ctx, const uint8_t *d_frames, const uint8_t *d_cmd, void
              ctx->y_affine && ctx->band_rows == 12 && c.obs_h % 12 == 0 && (c.obs_w / 4) * 12 <= kThreads)
         AGX_LAUNCH(0, k_ingest_pair12, dim3(bands, (c.num_envs + 1) / 2), dim3(256), lds + (size_t)2 * 12 * 2 * kRawW, S(stream), p,
                    (int)c.num_envs);
-    else if (ctx->tune.no_full == 0 && ctx->band12_ok && ctx->band_rows == 12)
-        AGX_LAUNCH(0, k_ingest_full12, dim3(bands, c.num_envs), dim3(256), band12_lds(ctx), S(stream), p);
-    else
-        AGX_LAUNCH(0, k_ingest<256>, dim3(bands, c.num_envs), dim3(256), lds, S(stream), p);
+    else launched = false;
+    if (!launched)
+#endif
+    {
+        // the headline form where its plan applies (12-row bands all full, affine source rows, adjacent x taps), the general
+        // band kernel otherwise
+        if (ctx->tune.no_full == 0 && ctx->band12_ok && ctx->band_rows == 12)
+            AGX_LAUNCH(0, k_ingest_full12, dim3(bands, c.num_envs), dim3(256), band12_lds(ctx), S(stream), p);
+        else
+            AGX_LAUNCH(0, k_ingest<256>, dim3(bands, c.num_envs), dim3(256), lds, S(stream), p);
+    }
     AGX_HIP(ctx, hipGetLastError());
     ctx->cur_head ^= 1;
     return AGX_OK;
@@ -965,17 +983,17 @@ int agx_fovea_fixed(agx_ctx *ctx, const void *d_action, int action_dtype, const 
         else                                                                                          \
             AGX_LAUNCH(1, (k_fovea_fixed<GeomR, MODE>), grid, block, lds, S(stream), gr, p);     \
     } while (0)
+#ifdef AGX_EXPERIMENTS
     // two physical slots per workgroup (whole launch resident at once, second frame's load hidden): measured a tie
-    // with the one-slot form at N=1024 (26.3 vs 25.8 us) - the launch is store-limited - so it is opt-in
-    const int pair_knob = ctx->tune.pair;
-    const bool pair = c.out_mode == AGX_OUT_RESIZE && c.frame_stack % 2 == 0 && pair_knob == 1;
-    if (pair) {
+    // with the one-slot form at N=1024 (26.3 vs 25.8 us) - the launch is store-limited
+    if (c.out_mode == AGX_OUT_RESIZE && c.frame_stack % 2 == 0 && ctx->tune.pair == 1) {
         const dim3 grid2(c.frame_stack / 2, c.num_envs);
         if (headline)
-            hipLaunchKernelGGL((k_fovea_fixed2<GS>), grid2, block, lds, S(stream), GS{}, p);
+            hipLaunchKernelGGL((k_fovea_fixed2<GS>), grid2, block, fixed2_lds(c), S(stream), GS{}, p);
         else
-            hipLaunchKernelGGL((k_fovea_fixed2<GeomR>), grid2, block, lds, S(stream), gr, p);
+            hipLaunchKernelGGL((k_fovea_fixed2<GeomR>), grid2, block, fixed2_lds(c), S(stream), gr, p);
     } else
+#endif
         switch (c.out_mode) {
             case AGX_OUT_RAW: LAUNCH(AGX_OUT_RAW); break;
             case AGX_OUT_MASK: LAUNCH(AGX_OUT_MASK); break;
@@ -996,6 +1014,10 @@ int agx_step_fixed(agx_ctx *ctx, const uint8_t *d_frames, const uint8_t *d_cmd, 
     if (!d_frames || !d_cmd || !d_obs) return fail(ctx, AGX_E_INVALID, "agx_step_fixed: null buffer");
     int rc = check_dt(ctx, d_action, action_dtype);
     if (rc) return rc;
+    // The step as the library ships it: the two stand-alone launches (ingest, then fovea), the fastest form measured.  The
+    // other forms of this call that were built and measured slower or equal (heterogeneous fused launch + tail, env-range
+    // parts on internal streams, one workgroup per env) live in the experiments build only.
+#ifdef AGX_EXPERIMENTS
     const bool headline = c.obs_h == 84 && c.obs_w == 84 && c.fov_h == 30 && c.fov_w == 30;
     // The heterogeneous launch (ingest bands + fovea of the untouched slots in one grid, written slot after) is
     // bit-identical and measured a tie at N=1024 (69.3 vs 67.9 us per step: it fills the ingest's drain but its
@@ -1109,39 +1131,39 @@ int agx_step_fixed(agx_ctx *ctx, const uint8_t *d_frames, const uint8_t *d_cmd, 
         }
         return AGX_OK;
     }
-    if (c.out_mode != AGX_OUT_RESIZE || ctx->ingest_t != 256 || !fused || c.obs_h != c.obs_w) {
-        // the two stand-alone launches, same results
-        rc = agx_ingest(ctx, d_frames, d_cmd, stream);
-        if (rc) return rc;
+    if (!(c.out_mode != AGX_OUT_RESIZE || ctx->ingest_t != 256 || !fused || c.obs_h != c.obs_w)) {
+        DeviceGuard g(c.device);
+        const IngestParams pi = ingest_params(ctx, d_frames, d_cmd);
+        FovParams pf = fov_params(ctx, d_action, action_dtype, nullptr, nullptr, d_obs, d_fov_loc, nullptr);
+        pf.cmd = d_cmd;
+        pf.phase = 1;
+        pf.head = ctx->head[ctx->cur_head];                  // the head BEFORE this step's ingest
+        const size_t lds = std::max(ingest_lds(ctx), fixed_lds(c));
+        const dim3 grid1(pi.nbands + c.frame_stack, c.num_envs), grid2(1, c.num_envs), block(kThreads);
+        using GS = GeomS<84, 84, 30, 30>;
+        const GeomR gr{c.obs_h, c.obs_w, c.fov_h, c.fov_w};
+        if (headline)
+            hipLaunchKernelGGL((k_step_fixed<GS>), grid1, block, lds, S(stream), GS{}, pi, pf);
+        else
+            hipLaunchKernelGGL((k_step_fixed<GeomR>), grid1, block, lds, S(stream), gr, pi, pf);
+        AGX_HIP(ctx, hipGetLastError());
+        ctx->cur_head ^= 1;
         if (mid_event) AGX_HIP(ctx, hipEventRecord(static_cast<hipEvent_t>(mid_event), S(stream)));
-        return agx_fovea_fixed(ctx, d_action, action_dtype, nullptr, d_obs, d_fov_loc, stream);
+        pf.phase = 2;
+        pf.head = ctx->head[ctx->cur_head];                  // the head AFTER the ingest
+        if (headline)
+            hipLaunchKernelGGL((k_step_fixed_tail<GS>), grid2, block, fixed_lds(c), S(stream), GS{}, pf);
+        else
+            hipLaunchKernelGGL((k_step_fixed_tail<GeomR>), grid2, block, fixed_lds(c), S(stream), gr, pf);
+        AGX_HIP(ctx, hipGetLastError());
+        ctx->cur_fov ^= 1;
+        return AGX_OK;
     }
-    DeviceGuard g(c.device);
-    const IngestParams pi = ingest_params(ctx, d_frames, d_cmd);
-    FovParams pf = fov_params(ctx, d_action, action_dtype, nullptr, nullptr, d_obs, d_fov_loc, nullptr);
-    pf.cmd = d_cmd;
-    pf.phase = 1;
-    pf.head = ctx->head[ctx->cur_head];                  // the head BEFORE this step's ingest
-    const size_t lds = std::max(ingest_lds(ctx), fixed_lds(c));
-    const dim3 grid1(pi.nbands + c.frame_stack, c.num_envs), grid2(1, c.num_envs), block(kThreads);
-    using GS = GeomS<84, 84, 30, 30>;
-    const GeomR gr{c.obs_h, c.obs_w, c.fov_h, c.fov_w};
-    if (headline)
-        hipLaunchKernelGGL((k_step_fixed<GS>), grid1, block, lds, S(stream), GS{}, pi, pf);
-    else
-        hipLaunchKernelGGL((k_step_fixed<GeomR>), grid1, block, lds, S(stream), gr, pi, pf);
-    AGX_HIP(ctx, hipGetLastError());
-    ctx->cur_head ^= 1;
+#endif
+    rc = agx_ingest(ctx, d_frames, d_cmd, stream);
+    if (rc) return rc;
     if (mid_event) AGX_HIP(ctx, hipEventRecord(static_cast<hipEvent_t>(mid_event), S(stream)));
-    pf.phase = 2;
-    pf.head = ctx->head[ctx->cur_head];                  // the head AFTER the ingest
-    if (headline)
-        hipLaunchKernelGGL((k_step_fixed_tail<GS>), grid2, block, fixed_lds(c), S(stream), GS{}, pf);
-    else
-        hipLaunchKernelGGL((k_step_fixed_tail<GeomR>), grid2, block, fixed_lds(c), S(stream), gr, pf);
-    AGX_HIP(ctx, hipGetLastError());
-    ctx->cur_fov ^= 1;
-    return AGX_OK;
+    return agx_fovea_fixed(ctx, d_action, action_dtype, nullptr, d_obs, d_fov_loc, stream);
 }
 
 int agx_fovea_peripheral(agx_ctx *ctx, const void *d_action, int action_dtype, const uint8_t *d_mask, float *d_obs,

@@ -47,11 +47,11 @@ __device__ __forceinline__ int2 uniform_load_i32x2(const int2 *ptr) {
 
 // D[yf][x] = sum_t hw[t] * u8 window[(lo + t)][x], x = xl + 8 k
 template <int T>
-__device__ __forceinline__ void flex3_hdwn(const unsigned char *src, float *dst, const float (&hw)[8], int ow, int kmax) {
+__device__ __forceinline__ void flex3_hdwn(const unsigned char *src, float *dst, const float (&hw)[8], int pitch, int kmax) {
     for (int k = 0; k < kmax; ++k) {
         float acc = 0.f;
 #pragma unroll
-        for (int q = 0; q < T; ++q) acc = fmaf(hw[q], (float)src[q * ow + 8 * k], acc);
+        for (int q = 0; q < T; ++q) acc = fmaf(hw[q], (float)src[q * pitch + 8 * k], acc);
         dst[8 * k] = acc;
     }
 }
@@ -130,25 +130,35 @@ __global__ __launch_bounds__(kThreads) void k_fovea_flexible3(G g, Flex3Params t
         }
     }
     const bool squeeze = rh > fh;                                     // rows only, fov_env.py:286
-    // ---- ... then the rows of this slot the window needs: [r, r + rh + 8) clipped to the frame (the 8 rows of slack are read
-    // with zero weights; what lies past the frame's end stays whatever the LDS held - bytes, hence finite as floats).  On
-    // average half of the 7 KB frame: the burst every resident workgroup starts with is halved.
+    // ---- ... then the part of this slot the window needs: rows [r, r + rh + 8) clipped to the frame (the 8 rows of slack are
+    // read with zero weights; what lies past the frame's end stays whatever the LDS held - bytes, hence finite as floats),
+    // and of each row only the dword-aligned column span that holds [c, c + rw).  On average a fifth of the 7 KB frame
+    // (round 2 fetched whole rows: half of it): the burst every resident workgroup of the launch starts with.
     const int wrows = min(rh + 8, oh - r);
-    const int wwords = (wrows * ow) >> 2;
-    const uint32_t *wsrc = fsrc + r * (ow >> 2);
+    const int span = ((c & 3) + rw + 3) >> 2;                         // dwords per image row (<= ow / 4)
+    const int wp = span * 4;                                          // image row pitch in bytes
+    const int wwords = wrows * span;
+    const int ow4s = ow >> 2;
+    const uint32_t *wsrc = fsrc + r * ow4s + (c >> 2);                // first dword of the window (wave-uniform)
+    const int wlimit = (fbytes >> 2) - 1 - (r * ow4s + (c >> 2));     // the slack may reach past the frame: clamped
+    const FastDiv dv_span(span);
+    auto src_of = [&](int i) {
+        const int y = dv_span.div(i);
+        return min(y * ow4s + (i - y * span), wlimit);
+    };
     constexpr int kFW = 7;
     uint32_t fw_[kFW];
 #pragma unroll
     for (int k = 0; k < kFW; ++k)
-        if (k * kThreads < wwords) fw_[k] = wsrc[min(tid + k * kThreads, wwords - 1)];
+        if (k * kThreads < wwords) fw_[k] = wsrc[src_of(min(tid + k * kThreads, wwords - 1))];
 
-    // ---- the taps this thread will use, requested now (L2 hits; they land under the frame load)
+    // ---- the taps of the first passes, requested now (L2 hits; they land under the window load)
     const int rstep = kThreads / ow;                                  // rows per sweep of the W passes (3 for ow = 84)
     const int xcol = tid % ow, yb = tid / ow;
     const int yf = tid >> 3, xl = tid & 7;                            // H-squeeze role
     const int4 yt = t.hy[rh * oh + min(tid, oh - 1)];
     int4 xt = make_int4(0, 0, 0, 0);
-    int wlo = 0, hlo = 0, Tw = 0, Th = 0;
+    int wlo = 0, hlo = 0, Tw = 0, Th = 0, wc_off = 0;
     float wc[16], hw[8];
 #pragma unroll
     for (int q = 0; q < 16; ++q) wc[q] = 0.f;
@@ -158,19 +168,7 @@ __global__ __launch_bounds__(kThreads) void k_fovea_flexible3(G g, Flex3Params t
         const int2 mw = uniform_load_i32x2(t.wc_meta + rw), mh = uniform_load_i32x2(t.hd_meta + rh);
         Tw = mw.x;
         Th = mh.x;
-        wlo = t.wc_lo[rw * ow + xcol];
-        const float4 *ws = reinterpret_cast<const float4 *>(t.wc_w + mw.y + xcol * Tw);
-        const float4 a0 = ws[0];
-        wc[0] = a0.x, wc[1] = a0.y, wc[2] = a0.z, wc[3] = a0.w;
-        if (Tw > 4) {
-            const float4 a1 = ws[1];
-            wc[4] = a1.x, wc[5] = a1.y, wc[6] = a1.z, wc[7] = a1.w;
-        }
-        if (Tw > 8) {
-            const float4 a2 = ws[2], a3 = ws[3];
-            wc[8] = a2.x, wc[9] = a2.y, wc[10] = a2.z, wc[11] = a2.w;
-            wc[12] = a3.x, wc[13] = a3.y, wc[14] = a3.z, wc[15] = a3.w;
-        }
+        wc_off = mw.y;
         const int yfc = min(yf, fh - 1);
         hlo = t.hd_lo[rh * fh + yfc];
         const float4 *hs = reinterpret_cast<const float4 *>(t.hd_w + mh.y + yfc * Th);
@@ -183,25 +181,42 @@ __global__ __launch_bounds__(kThreads) void k_fovea_flexible3(G g, Flex3Params t
     } else {
         xt = *reinterpret_cast<const int4 *>(t.wf + rw * ow + xcol);
     }
-    // ---- LDS image: the window rows (row r of the frame is row 0 of the image), the row taps
+    // ---- LDS image: the window (row r, column 4 (c / 4) of the frame is byte 0 of the image), the row taps
 #pragma unroll
     for (int k = 0; k < kFW; ++k)
         if (tid + k * kThreads < wwords) reinterpret_cast<uint32_t *>(raw)[tid + k * kThreads] = fw_[k];
-    for (int i = tid + kFW * kThreads; i < wwords; i += kThreads) reinterpret_cast<uint32_t *>(raw)[i] = wsrc[i];
+    for (int i = tid + kFW * kThreads; i < wwords; i += kThreads) reinterpret_cast<uint32_t *>(raw)[i] = wsrc[src_of(i)];
     if (tid < oh) ytab_s[tid] = yt;
     for (int i = tid + kThreads; i < oh; i += kThreads) ytab_s[i] = t.hy[rh * oh + i];
+    // ---- the composed W taps are not needed before the second pass: requested only now, when the window's registers are
+    // free again (all of it up front took the kernel to 76 VGPRs = six waves per SIMD)
+    if (squeeze) {
+        wlo = t.wc_lo[rw * ow + xcol];
+        const float4 *ws = reinterpret_cast<const float4 *>(t.wc_w + wc_off + xcol * Tw);
+        const float4 a0 = ws[0];
+        wc[0] = a0.x, wc[1] = a0.y, wc[2] = a0.z, wc[3] = a0.w;
+        if (Tw > 4) {
+            const float4 a1 = ws[1];
+            wc[4] = a1.x, wc[5] = a1.y, wc[6] = a1.z, wc[7] = a1.w;
+        }
+        if (Tw > 8) {
+            const float4 a2 = ws[2], a3 = ws[3];
+            wc[8] = a2.x, wc[9] = a2.y, wc[10] = a2.z, wc[11] = a2.w;
+            wc[12] = a3.x, wc[13] = a3.y, wc[14] = a3.z, wc[15] = a3.w;
+        }
+    }
     __syncthreads();
 
-    const unsigned char *win = raw + c;                               // window origin inside the LDS image
+    const unsigned char *win = raw + (c & 3);                         // window origin inside the LDS image (pitch wp)
     const float *E;
     if (squeeze) {
         // ---- D = Hdwn . crop   (columns up to max(rw, Tw) so that every D element the W pass reads is finite)
         if (yf < fh) {
             const int kmax = (max(rw, Tw) + 7) >> 3;
-            const unsigned char *src = win + hlo * ow + xl;
+            const unsigned char *src = win + hlo * wp + xl;
             float *dst = R1 + yf * t.dp + xl;
-            if (Th <= 4) flex3_hdwn<4>(src, dst, hw, ow, kmax);
-            else flex3_hdwn<8>(src, dst, hw, ow, kmax);
+            if (Th <= 4) flex3_hdwn<4>(src, dst, hw, wp, kmax);
+            else flex3_hdwn<8>(src, dst, hw, wp, kmax);
         }
         __syncthreads();
         // ---- E = D . Wcomp^T, into R0 (the raw bytes are dead)
@@ -218,12 +233,12 @@ __global__ __launch_bounds__(kThreads) void k_fovea_flexible3(G g, Flex3Params t
         // ---- E = crop . Wfin^T, straight from the u8 window
         if (yb < rstep) {
             const int kmax = (rh + rstep - 1) / rstep;
-            const unsigned char *c0 = win + yb * ow + xt.x, *c1 = win + yb * ow + xt.y;
+            const unsigned char *c0 = win + yb * wp + xt.x, *c1 = win + yb * wp + xt.y;
             const float wa = __int_as_float(xt.z), wb = __int_as_float(xt.w);
             float *dst = R1 + yb * ow + xcol;
 #pragma unroll 2
             for (int k = 0; k < kmax; ++k)
-                dst[k * rstep * ow] = fmaf(wb, (float)c1[k * rstep * ow], wa * (float)c0[k * rstep * ow]);
+                dst[k * rstep * ow] = fmaf(wb, (float)c1[k * rstep * wp], wa * (float)c0[k * rstep * wp]);
         }
         E = R1;
     }

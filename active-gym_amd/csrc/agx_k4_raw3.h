@@ -218,15 +218,24 @@ __global__ __launch_bounds__(kThreads) void k_fovea_flexible_raw3(G g, FlexRawPa
         return;
     }
 
-    // ---- squeeze path: window rows [r, r + rh + 8) clipped to the frame (slack rows are read with zero weights)
+    // ---- squeeze path: window rows [r, r + rh + 8) clipped to the frame (slack rows are read with zero weights), and of each
+    // row the dword-aligned column span that holds [c, c + rw) (as k_fovea_flexible3 does)
     const int wrows = min(rh + 8, oh - r);
-    const int wwords = (wrows * ow) >> 2;
-    const uint32_t *wsrc = reinterpret_cast<const uint32_t *>(frame) + r * ow4;
+    const int span = ((c & 3) + rw + 3) >> 2;
+    const int wp = span * 4;
+    const int wwords = wrows * span;
+    const uint32_t *wsrc = reinterpret_cast<const uint32_t *>(frame) + r * ow4 + (c >> 2);
+    const int wlimit = (fbytes >> 2) - 1 - (r * ow4 + (c >> 2));
+    const FastDiv dv_span(span);
+    auto src_of = [&](int i) {
+        const int y = dv_span.div(i);
+        return min(y * ow4 + (i - y * span), wlimit);
+    };
     constexpr int kFW = 7;
     uint32_t fw_[kFW];
 #pragma unroll
     for (int k = 0; k < kFW; ++k)
-        if (k * kThreads < wwords) fw_[k] = wsrc[min(tid + k * kThreads, wwords - 1)];
+        if (k * kThreads < wwords) fw_[k] = wsrc[src_of(min(tid + k * kThreads, wwords - 1))];
     const int rstep = kThreads / ow;
     const int xcol = tid % ow, yb = tid / ow;
     const int yf = tid >> 3, xl = tid & 7;
@@ -238,6 +247,24 @@ __global__ __launch_bounds__(kThreads) void k_fovea_flexible_raw3(G g, FlexRawPa
     for (int q = 0; q < 16; ++q) wc[q] = 0.f;
 #pragma unroll
     for (int q = 0; q < 8; ++q) hw[q] = 0.f;
+    const int yfc = min(yf, fh - 1);
+    const int hlo = t.hd_lo[rh * fh + yfc];
+    {
+        const float4 *hs = reinterpret_cast<const float4 *>(t.hd_w + mh.y + yfc * Th);
+        const float4 b0 = hs[0];
+        hw[0] = b0.x, hw[1] = b0.y, hw[2] = b0.z, hw[3] = b0.w;
+        if (Th > 4) {
+            const float4 b1 = hs[1];
+            hw[4] = b1.x, hw[5] = b1.y, hw[6] = b1.z, hw[7] = b1.w;
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < kFW; ++k)
+        if (tid + k * kThreads < wwords) reinterpret_cast<uint32_t *>(raw)[tid + k * kThreads] = fw_[k];
+    for (int i = tid + kFW * kThreads; i < wwords; i += kThreads) reinterpret_cast<uint32_t *>(raw)[i] = wsrc[src_of(i)];
+    if (tid < oh) *reinterpret_cast<int4 *>(ytab_s + tid) = yt;
+    for (int i = tid + kThreads; i < rh; i += kThreads) ytab_s[i] = t.hb[rh * oh + i];
+    // the composed W taps are needed only after the first pass: requested now that the window's registers are free
     const int wlo = t.wb_lo[rw * ow + xcol];
     {
         const float4 *ws = reinterpret_cast<const float4 *>(t.wb_w + mw.y + xcol * Tw);
@@ -253,32 +280,15 @@ __global__ __launch_bounds__(kThreads) void k_fovea_flexible_raw3(G g, FlexRawPa
             wc[12] = a3.x, wc[13] = a3.y, wc[14] = a3.z, wc[15] = a3.w;
         }
     }
-    const int yfc = min(yf, fh - 1);
-    const int hlo = t.hd_lo[rh * fh + yfc];
-    {
-        const float4 *hs = reinterpret_cast<const float4 *>(t.hd_w + mh.y + yfc * Th);
-        const float4 b0 = hs[0];
-        hw[0] = b0.x, hw[1] = b0.y, hw[2] = b0.z, hw[3] = b0.w;
-        if (Th > 4) {
-            const float4 b1 = hs[1];
-            hw[4] = b1.x, hw[5] = b1.y, hw[6] = b1.z, hw[7] = b1.w;
-        }
-    }
-#pragma unroll
-    for (int k = 0; k < kFW; ++k)
-        if (tid + k * kThreads < wwords) reinterpret_cast<uint32_t *>(raw)[tid + k * kThreads] = fw_[k];
-    for (int i = tid + kFW * kThreads; i < wwords; i += kThreads) reinterpret_cast<uint32_t *>(raw)[i] = wsrc[i];
-    if (tid < oh) *reinterpret_cast<int4 *>(ytab_s + tid) = yt;
-    for (int i = tid + kThreads; i < rh; i += kThreads) ytab_s[i] = t.hb[rh * oh + i];
     __syncthreads();
 
     // ---- D = Hdwn . crop   (columns up to max(rw, Tw): every D element the W pass reads is finite)
     if (yf < fh) {
         const int kmax = (max(rw, Tw) + 7) >> 3;
-        const unsigned char *src = raw + c + hlo * ow + xl;
+        const unsigned char *src = raw + (c & 3) + hlo * wp + xl;
         float *dst = R1 + yf * t.dp + xl;
-        if (Th <= 4) flex3_hdwn<4>(src, dst, hw, ow, kmax);
-        else flex3_hdwn<8>(src, dst, hw, ow, kmax);
+        if (Th <= 4) flex3_hdwn<4>(src, dst, hw, wp, kmax);
+        else flex3_hdwn<8>(src, dst, hw, wp, kmax);
     }
     __syncthreads();
     // ---- E = D . (Wbck Wdwn)^T into R0, pitch ow (the raw bytes are dead)

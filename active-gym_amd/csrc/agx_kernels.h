@@ -23,4 +23,6 @@
 #include "agx_k3_per3.h"
 #include "agx_k4_flex3.h"
 #include "agx_k4_raw3.h"
-#include "agx_step_env.h"
+#ifdef AGX_EXPERIMENTS
+#include "experiments/agx_experiments.h"   // measured dead ends: tools/ and the variants test only, never in libagx.so
+#endif

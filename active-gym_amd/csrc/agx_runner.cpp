@@ -413,8 +413,8 @@ int agxr_step(agxr_runner *r, const int32_t *motor, uint8_t *frames, uint8_t *cm
     return rc ? rc : agxr_step_wait(r, -1);
 }
 
-int agxr_reset(agxr_runner *r, const int32_t *idx, int32_t k, const int32_t *noops, uint8_t *frames, int64_t env_stride,
-               uint8_t *cmd) {
+static int reset_impl(agxr_runner *r, const int32_t *idx, int32_t k, const int32_t *noops, uint8_t *frames, int64_t env_stride,
+                      uint8_t *cmd, bool packed) {
     if (!r) return AGXR_E_INVALID;
     if (!idx || !noops || !frames || !cmd || k < 0) return fail(r, AGXR_E_INVALID, "agxr_reset: bad argument");
     if (r->in_flight) return fail(r, AGXR_E_STATE, "agxr_reset: a step is in flight (agxr_step_wait(-1) first)");
@@ -447,13 +447,24 @@ int agxr_reset(agxr_runner *r, const int32_t *idx, int32_t k, const int32_t *noo
                 }
                 if (e.game_over()) e.reset_game();
             }
-            if (r->cfg.gray_frames) e.screen_gray(frames + (size_t)i * env_stride);
-            else e.screen_rgb(frames + (size_t)i * env_stride);
+            uint8_t *dst = frames + (size_t)(packed ? j : i) * env_stride;    // packed: the j-th reset env's screen in row j
+            if (r->cfg.gray_frames) e.screen_gray(dst);
+            else e.screen_rgb(dst);
             r->lives[i] = e.lives();
             cmd[i] = (uint8_t)(1 | clear);
         }
     });
     return AGXR_OK;
+}
+
+int agxr_reset(agxr_runner *r, const int32_t *idx, int32_t k, const int32_t *noops, uint8_t *frames, int64_t env_stride,
+               uint8_t *cmd) {
+    return reset_impl(r, idx, k, noops, frames, env_stride, cmd, false);
+}
+
+int agxr_reset_packed(agxr_runner *r, const int32_t *idx, int32_t k, const int32_t *noops, uint8_t *frames, int64_t row_stride,
+                      uint8_t *cmd) {
+    return reset_impl(r, idx, k, noops, frames, row_stride, cmd, true);
 }
 
 int agxr_get_state(const agxr_runner *r, int32_t *lives, uint8_t *life_termination) {

@@ -28,8 +28,8 @@
 // its slower team.  Alternating the job order between odd and even envs changed nothing (74.5 us); a staggered start
 // made it monotonically slower (77-92 us).  DESIGN.md section 3, "One workgroup per env".
 #pragma once
-#include "agx_k1_ingest.h"
-#include "agx_k2_fixed.h"
+#include "../agx_k1_ingest.h"
+#include "../agx_k2_fixed.h"
 
 namespace agx {
 

@@ -550,6 +550,7 @@ def main():
                        "parallelism": f"env-shard x{world}, no collective"},
             "roofline": roof, "kernels": kernels, "build": _build_info(),
             "per_gpu": [n * K / t_ for t_ in per_rank], "per_gpu_unit": "env steps/s of each rank over its own timed region",
+            "control_plane": (dist.get_backend() if dist is not None and dist.is_initialized() else "none"),
         }
         if world > 1:
             out["config"]["games"] = "one synthetic frame source per GPU (the game mix only changes the emulator, never the shapes)"

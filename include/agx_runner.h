@@ -84,6 +84,10 @@ AGXR_API int agxr_step_wait(agxr_runner *r, int32_t chunk);
  * frames + i * env_stride (bytes); cmd[i] = 1 | AGX_CMD_CLEAR for a full reset; other envs get AGX_CMD_SKIP. */
 AGXR_API int agxr_reset(agxr_runner *r, const int32_t *idx, int32_t k, const int32_t *noops, uint8_t *frames,
                         int64_t env_stride, uint8_t *cmd);
+/* The same reset with the screens PACKED: env idx[j]'s reset screen goes to frames + j * row_stride (the autoreset inside a
+ * vector step uploads the k reset screens as one contiguous copy; cmd stays indexed by env). */
+AGXR_API int agxr_reset_packed(agxr_runner *r, const int32_t *idx, int32_t k, const int32_t *noops, uint8_t *frames,
+                               int64_t row_stride, uint8_t *cmd);
 
 /* lives i32[N], life_termination u8[N] (either may be NULL) */
 AGXR_API int agxr_get_state(const agxr_runner *r, int32_t *lives, uint8_t *life_termination);

@@ -551,6 +551,137 @@ def make_record(fov_env, gym):
         return [_record_case(fov_env, gym, k, k, 900 + i, tmp) for i, k in enumerate(("base", "fixed", "flex", "per"))]
 
 
+# ------------------------------------------------------------------ record buffers through the WHOLE Atari stack
+def _record_atari_case(atari_env, kind, seed):
+    """The reference's own AtariBaseEnv / AtariFixedFovealEnv / AtariFlexibleFovealEnv / AtariFixedFovealPeripheralEnv with
+    record=True (atari_env.py:174-192, fov_env.py:34-37,51-102,152-154,161-163,218-220,253-256,265-267,352-354,370-373)
+    over a ScriptedALE with real-size 210x160 screens: what the record buffers hold after two finished episodes and the
+    start of a third - frames (render(): atari_env.py:165-169), full states, actions, rewards, dones, infos, fov_loc /
+    fov_res - for the drop-in's device path to reproduce (tests/test_gpu_env.py::test_record_buffers_match_reference_run).
+    For THIS case only cv2.resize is the oracle's restatement of OpenCV's 8-bit INTER_LINEAR (the control flow and the
+    buffer contents are the reference's; that arithmetic stays "parity unpinned")."""
+    import zlib
+    import cv2
+    from oracle import oracle as _O
+    obs, fov, fs = (84, 84), (30, 30), 2
+    ale = ScriptedALE(seed=seed, screen_hw=(210, 160), n_actions=4, start_lives=2, p_life=0.015, p_over=0.01)
+    _STATE["next_ale"] = ale
+    _STATE["antialias"] = True
+    random.seed(seed)
+    noops = []
+    orig_rr, orig_resize = random.randrange, cv2.resize
+
+    def rec_randrange(n):
+        v = orig_rr(n)
+        noops.append(v)
+        return v
+
+    def resize(img, dsize, interpolation=None):
+        img = np.asarray(img)
+        if img.ndim == 3 and img.shape[-1] == 1:
+            return _O.cv_resize_linear_u8(img[..., 0], dsize)
+        if img.ndim == 3:
+            return np.stack([_O.cv_resize_linear_u8(np.ascontiguousarray(img[..., c]), dsize) for c in range(img.shape[-1])], -1)
+        return _O.cv_resize_linear_u8(img, dsize)
+
+    atari_env.random.randrange = rec_randrange
+    cv2.resize = resize
+    try:
+        args = atari_env.AtariEnvArgs(game="scripted", seed=seed, obs_size=obs, frame_stack=fs, action_repeat=4, record=True,
+                                      fov_size=fov, fov_init_loc=(3, 5), sensory_action_mode="absolute", resize_to_full=True,
+                                      mask_out=False, peripheral_res=(20, 20))
+        env = {"base": atari_env.AtariBaseEnv, "fixed": atari_env.AtariFixedFovealEnv, "flex": atari_env.AtariFlexibleFovealEnv,
+               "per": atari_env.AtariFixedFovealPeripheralEnv}[kind](args)
+        base = env
+        while not hasattr(base, "prev_record_buffer"):
+            base = base.env
+        rng = np.random.default_rng(seed + 1)
+        drive = [(1, 0, 0, 0, 0)]
+        env.reset()
+        episodes = 0
+        for t in range(400):
+            motor = int(rng.integers(0, 4))
+            sens = rng.integers(-4, 70, size=2)
+            typ = int(rng.integers(0, 2)) if kind == "flex" else 0
+            if typ == 1:
+                sens = rng.integers(8, 70, size=2)
+            if kind == "base":
+                _, _, d, _, _ = env.step(motor)
+            else:
+                act = {"motor_action": motor, "sensory_action": sens.astype(np.int64 if kind == "flex" else np.float64)}
+                if kind == "flex":
+                    act["sensory_action_type"] = np.array((typ,))
+                _, _, d, _, _ = env.step(act)
+            drive.append((0, motor, int(sens[0]), int(sens[1]), typ))
+            if d:
+                episodes += 1
+                env.reset()
+                drive.append((1, 0, 0, 0, 0))
+                if episodes == 2:
+                    break
+        assert episodes == 2, "raise the step cap or the event rates"
+        for _ in range(3):                       # the start of a third episode stays in record_buffer
+            motor = int(rng.integers(0, 4))
+            sens = rng.integers(0, 50, size=2)
+            if kind == "base":
+                _, _, d, _, _ = env.step(motor)
+            else:
+                act = {"motor_action": motor, "sensory_action": sens.astype(np.int64 if kind == "flex" else np.float64)}
+                if kind == "flex":
+                    act["sensory_action_type"] = np.array((0,))
+                _, _, d, _, _ = env.step(act)
+            drive.append((0, motor, int(sens[0]), int(sens[1]), 0))
+            if d:
+                break
+    finally:
+        atari_env.random.randrange = orig_rr
+        cv2.resize = orig_resize
+    rec = {"kind": kind, "seed": seed, "obs_size": np.array(obs), "fov_size": np.array(fov), "frame_stack": fs, "action_repeat": 4,
+           "init_loc": np.array((3, 5)), "peripheral_res": np.array((20, 20)), "start_lives": 2, "p_life": 0.015, "p_over": 0.01,
+           "noops": np.array(noops, dtype=np.int64), "drive": np.array(drive, dtype=np.int64)}
+
+    def dump(tag, buf):
+        rec[f"{tag}_keys"] = np.array(list(buf.keys()))                      # insertion order, as the reference builds it
+        for k in ("rgb", "state", "action", "reward", "done", "truncated", "info", "return_reward", "fov_loc", "fov_res"):
+            if k in buf:
+                rec[f"{tag}_len_{k}"] = len(buf[k])
+        rgb = np.stack(buf["rgb"])
+        assert rgb.dtype == np.uint8 and rgb.shape[1:] == (256, 256, 3)
+        rec[f"{tag}_rgb_crc"] = np.array([zlib.crc32(np.ascontiguousarray(f).tobytes()) for f in rgb], dtype=np.int64)
+        rec[f"{tag}_rgb_first"] = rgb[0][::8, ::8].copy()                    # a thumbnail for diagnosis
+        st = np.stack(buf["state"])
+        assert st.dtype == np.float64
+        u8 = np.rint(st * 255.0).astype(np.uint8)
+        assert np.array_equal((u8.astype(np.float32) / np.float32(255.0)).astype(np.float64), st), "states must be k/255"
+        rec[f"{tag}_state_crc"] = np.array([zlib.crc32(np.ascontiguousarray(f).tobytes()) for f in u8], dtype=np.int64)
+        rec[f"{tag}_state_last_u8"] = u8[-1]
+        for k in ("action", "reward", "done", "truncated", "return_reward"):
+            rec[f"{tag}_{k}"] = np.array(buf[k])
+        for k in ("fov_loc", "fov_res"):
+            if k in buf:
+                rec[f"{tag}_{k}"] = np.array(buf[k], dtype=np.int64)
+        for k in ("fov_size", "peripheral_res"):
+            if k in buf:
+                rec[f"{tag}_{k}"] = np.array(buf[k])
+        infos = buf["info"]
+        for k in ("raw_reward", "reward", "ep_len"):
+            rec[f"{tag}_info_{k}"] = np.array([i[k] for i in infos], dtype=np.float64)
+        rec[f"{tag}_info_keys"] = np.array(list(infos[-1].keys())) if infos else np.array([])
+        for k in ("fov_loc", "fov_res"):
+            if infos and k in infos[-1]:
+                rec[f"{tag}_info_{k}"] = np.array([i[k] for i in infos], dtype=np.int64)
+
+    dump("prev", base.prev_record_buffer)
+    dump("cur", base.record_buffer)
+    path = os.path.join(HERE, f"record_atari_{kind}.npz")
+    np.savez_compressed(path, **rec)
+    return path
+
+
+def make_record_atari(atari_env):
+    return [_record_atari_case(atari_env, k, 950 + i) for i, k in enumerate(("base", "fixed", "flex", "per"))]
+
+
 # ------------------------------------------------------------------ spaces / attributes
 def make_spaces(fov_env, gym):
     """What each wrapper hands to gymnasium's space constructors and the attributes callers read
@@ -709,7 +840,11 @@ def main():
     _install_standins()
     fov_env, atari_env, dmc_env = _load_reference()
     gym = sys.modules["gymnasium"]
-    paths = make_fovea(fov_env, gym) + make_atari(atari_env) + make_record(fov_env, gym) + make_dmc(dmc_env) + make_spaces(fov_env, gym) + make_cv2()
+    if sys.argv[1:] == ["record_atari"]:          # only the whole-stack record goldens (the other files stay byte-identical)
+        paths = make_record_atari(atari_env)
+    else:
+        paths = (make_fovea(fov_env, gym) + make_atari(atari_env) + make_record(fov_env, gym) + make_record_atari(atari_env) +
+                 make_dmc(dmc_env) + make_spaces(fov_env, gym) + make_cv2())
     total = 0
     for p in paths:
         sz = os.path.getsize(p)

@@ -72,7 +72,7 @@ def test_runner_library_exports_header_surface():
     path = m.build_runner()
     src = open(os.path.join(REPO, "include", "agx_runner.h")).read()
     names = sorted(set(re.findall(r"^AGXR_API[^;(]*?\b(agxr_\w+)\s*\(", src, flags=re.M)))
-    assert len(names) == 11
+    assert len(names) == 12
     handle = ctypes.CDLL(path)
     for name in names:
         assert hasattr(handle, name), name

@@ -284,6 +284,84 @@ def test_recording_buffer_keys(tmp_path):
     env.close()
 
 
+@pytest.mark.parametrize("kind,factory", [("base", "AtariBaseEnv"), ("fixed", "AtariFixedFovealEnv"), ("flex", "AtariFlexibleFovealEnv"),
+                                          ("per", "AtariFixedFovealPeripheralEnv")])
+def test_record_buffers_match_reference_run(kind, factory, tmp_path):
+    """f2 as a parity row: the drop-in envs with record=True, through the real device path, against the record buffers the
+    REFERENCE's own env stack produced over the same scripted emulator, actions and no-op draws
+    (tests/golden/record_atari_*.npz from tests/golden/make_golden.py::_record_atari_case: fov_env.py:34-37,51-102,152-154,
+    253-256,370-373 on top of atari_env.py:73-169).  Contents, not only keys: every recorded full state (u8 numerators, CRC:
+    bit-exact), every 256x256 frame (CRC), actions, cumulative / returned rewards, dones, truncated flags, infos incl.
+    fov_loc / fov_res, key order, and the saved .pt."""
+    import os
+    import zlib
+    import active_gym
+    from active_gym import AtariEnvArgs
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", f"record_atari_{kind}.npz"))
+    seed = int(g["seed"])
+    args = AtariEnvArgs(game="scripted", seed=seed, obs_size=tuple(int(v) for v in g["obs_size"]), frame_stack=int(g["frame_stack"]),
+                        action_repeat=int(g["action_repeat"]), record=True, fov_size=tuple(int(v) for v in g["fov_size"]),
+                        fov_init_loc=tuple(int(v) for v in g["init_loc"]), sensory_action_mode="absolute", resize_to_full=True,
+                        mask_out=False, peripheral_res=tuple(int(v) for v in g["peripheral_res"]), antialias=True,
+                        frame_format="gray",               # the reference reads ale.getScreenGrayscale() (atari_env.py:74)
+                        frame_source=lambda a, i: ScriptedALE(seed=seed, screen_hw=(210, 160), n_actions=4,
+                                                              start_lives=int(g["start_lives"]), p_life=float(g["p_life"]),
+                                                              p_over=float(g["p_over"])))
+    env = getattr(active_gym, factory)(args)
+    noops = iter(g["noops"].tolist())
+    env.unwrapped._core.runner.noop_fn = lambda: int(next(noops))
+    rw = env
+    while not hasattr(rw, "prev_record_buffer"):
+        rw = rw.env
+    for is_reset, motor, s0, s1, typ in g["drive"].tolist():
+        if is_reset:
+            env.reset()
+        elif kind == "base":
+            env.step(motor)
+        else:
+            a = {"motor_action": motor, "sensory_action": np.array((s0, s1), np.int64 if kind == "flex" else np.float64)}
+            if kind == "flex":
+                a["sensory_action_type"] = np.array((typ,))
+            env.step(a)
+
+    def check(tag, buf):
+        assert list(buf.keys()) == g[f"{tag}_keys"].tolist(), (tag, list(buf.keys()))
+        for k in ("rgb", "state", "action", "reward", "done", "truncated", "info", "return_reward", "fov_loc", "fov_res"):
+            if f"{tag}_len_{k}" in g.files:
+                assert len(buf[k]) == int(g[f"{tag}_len_{k}"]), (tag, k, len(buf[k]))
+        rgb = np.stack(buf["rgb"])
+        assert rgb.dtype == np.uint8 and rgb.shape[1:] == (256, 256, 3)
+        assert np.array_equal(rgb[0][::8, ::8], g[f"{tag}_rgb_first"])
+        assert [zlib.crc32(np.ascontiguousarray(f).tobytes()) for f in rgb] == g[f"{tag}_rgb_crc"].tolist()
+        st = np.stack(buf["state"])
+        assert st.dtype == np.float64                         # the reference records its float64 full state (fov_env.py:59,74)
+        u8 = np.rint(st * 255.0).astype(np.uint8)
+        assert np.array_equal((u8.astype(np.float32) / np.float32(255.0)).astype(np.float64), st)
+        assert np.array_equal(u8[-1], g[f"{tag}_state_last_u8"])
+        assert [zlib.crc32(np.ascontiguousarray(f).tobytes()) for f in u8] == g[f"{tag}_state_crc"].tolist()
+        for k in ("action", "reward", "done", "truncated", "return_reward"):
+            assert np.array_equal(np.array(buf[k]), g[f"{tag}_{k}"]), (tag, k, buf[k])
+        for k in ("fov_loc", "fov_res", "fov_size", "peripheral_res"):
+            if f"{tag}_{k}" in g.files:
+                assert np.array_equal(np.array(buf[k], dtype=np.int64), g[f"{tag}_{k}"]), (tag, k)
+        for k in ("raw_reward", "reward", "ep_len"):
+            assert np.array_equal(np.array([i[k] for i in buf["info"]], dtype=np.float64), g[f"{tag}_info_{k}"]), (tag, k)
+        assert list(buf["info"][-1].keys()) == g[f"{tag}_info_keys"].tolist()
+        for k in ("fov_loc", "fov_res"):
+            if f"{tag}_info_{k}" in g.files:
+                assert np.array_equal(np.array([i[k] for i in buf["info"]], dtype=np.int64), g[f"{tag}_info_{k}"]), (tag, k)
+
+    check("prev", rw.prev_record_buffer)
+    check("cur", rw.record_buffer)
+    path = str(tmp_path / f"{kind}.pt")
+    rw.save_record_to_file(path)
+    saved = torch.load(path, weights_only=False)              # written by the line above
+    assert list(saved.keys()) == g["prev_keys"].tolist() and isinstance(saved["rgb"], str)
+    assert np.array_equal(np.array(saved["reward"]), g["prev_reward"])
+    assert saved["state"] == [0] * len(g["prev_reward"])     # the reference replaces the states by zeros on save (fov_env.py:100)
+    env.close()
+
+
 def test_bench_contract_json():
     """bench.py prints ONE JSON line with the driver's contract fields (small, quick configuration)."""
     import json, os, subprocess, sys
@@ -304,6 +382,10 @@ def test_bench_contract_json():
     c = d["cpu_baseline"]
     assert c["kind"] == "port" and c["cores"] >= 1 and c["value"] > 0 and "sample" in c
     assert abs(d["value"] - 64 * 8 / (d["ms_per_step"] * 8e-3)) / d["value"] < 1e-6
+    # the timed region is K plain steps: no HIP event is created for, handed to or recorded around any of its launches
+    # (the per-kernel durations behind `roofline` come from a sampling pass that follows it)
+    assert d["events_in_timed_region"] == 0 and d["preroll"] >= 0
+    assert r["launches_timed"] >= 16 and "sampling pass" in r["timing"]
 
 
 @pytest.mark.parametrize("kind", ["fixed", "flex", "per"])

@@ -92,3 +92,26 @@ def test_bench_two_gpu_rehearsal_prints_one_line_with_per_gpu_values():
     assert len(d["per_gpu"]) == 2 and all(v > 0 for v in d["per_gpu"])
     assert d["value"] <= sum(d["per_gpu"]) * 1.0001          # whole-job rate uses the slowest rank's time
     assert "cpu_baseline" not in d and "e2e" not in d
+
+
+def test_bench_single_rank_over_rccl():
+    """The control plane of the multi-GPU bench on the real backend: one rank, process group forced, backend nccl (= RCCL).
+    Executes, on the GPU, what the 8-GPU run depends on and a one-GPU lease otherwise never runs: RCCL initialisation with a
+    bound device, barrier(device_ids=...), all_reduce(MAX) of the timed region and the all_gather behind `per_gpu`."""
+    import socket
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ, AGX_BENCH_FORCE_DIST="1", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK="0", WORLD_SIZE="1",
+               LOCAL_RANK="0", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    env.pop("AGX_BENCH_BACKEND", None)
+    env.pop("AGX_BENCH_SHARE_GPU", None)
+    r = subprocess.run([sys.executable, os.path.join(REPO, "bench.py"), "--steps", "24", "--warmup", "4", "--envs", "256",
+                        "--no-cpu-baseline", "--no-e2e"], capture_output=True, text=True, cwd=REPO, env=env, timeout=900)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 1 and len(d["per_gpu"]) == 1 and d["per_gpu"][0] > 0
+    assert abs(d["per_gpu"][0] - d["value"]) / d["value"] < 1e-6          # one rank: its own rate is the whole job's
+    assert d["control_plane"] == "nccl"

@@ -88,3 +88,37 @@ def test_scalar_sensory_action_is_broadcast_like_np_clip():
     assert one(torch.tensor(5.5), 2).tolist() == [[5.5, 5.5]]
     assert one(np.array([4, 9]), 2).tolist() == [[4, 9]]
     assert one(torch.tensor([[1.0, 2.0]]), 2).tolist() == [[1.0, 2.0]]
+
+
+def test_device_guard_restore_semantics_with_a_mocked_runtime(tmp_path):
+    import os
+    """agx_device_guard.h (what every C-ABI entry point opens) against a mocked device runtime: a context on device d != 0
+    used from a thread on another device - switch, restore, nesting, failing set / get.  An 8-GPU node runs this for real;
+    a one-GPU box cannot (tests/test_gpu_env.py::test_vec_env_on_a_device_that_is_not_the_current_one is skipped there)."""
+    import subprocess
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = str(tmp_path / "device_guard_harness")
+    subprocess.run(["g++", "-std=c++17", "-Wall", "-Werror", "-I", os.path.join(repo, "active-gym_amd", "csrc"),
+                    os.path.join(repo, "tests", "device_guard_harness.cpp"), "-o", exe], check=True, timeout=120)
+    r = subprocess.run([exe], capture_output=True, text=True, timeout=60)
+    assert r.returncode == 0 and r.stdout.strip() == "ok", r.stdout + r.stderr
+
+
+def test_every_device_entry_point_opens_a_device_guard():
+    import os
+    """Static audit of agx_api.hip: every extern "C" entry point that launches, copies or allocates names the context's
+    device through DeviceGuard before its first HIP call (ordinal != 0 safety, SURVEY 8e)."""
+    import re
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    src = open(os.path.join(repo, "active-gym_amd", "csrc", "agx_api.hip")).read()
+    body = src[src.index('extern "C" {'):]
+    funcs = re.findall(r"^(?:int|int64_t|const char \*)\s*(agx_\w+)\(.*?^}", body, flags=re.S | re.M)
+    assert len(funcs) >= 20
+    for m in re.finditer(r"^(?:int|int64_t|const char \*)\s*(agx_\w+)\((.*?)^}", body, flags=re.S | re.M):
+        name, text = m.group(1), m.group(2)
+        touches = re.search(r"hipLaunchKernelGGL|AGX_LAUNCH|hipMemcpy|hipMemset|hipMalloc|hipFree|hipEventRecord|hipStream", text)
+        delegates = re.search(r"return (?:stack_launch|agx_ingest|agx_fovea_fixed)\(", text)
+        if touches:
+            first = touches.start()
+            guard = text.find("DeviceGuard g(")
+            assert 0 <= guard < first or (delegates and guard < 0 and name == "agx_step_fixed"), name

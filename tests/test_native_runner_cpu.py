@@ -59,8 +59,13 @@ def test_native_runner_equals_python_runner(ar, clip, training, n_act):
             n_done += len(d)
             ra = np.zeros((N, 1, 210, 160, 3), np.uint8)
             rb = np.zeros((N, 1, 210, 160, 3), np.uint8)
-            assert np.array_equal(py.reset(d, out=ra), nv.reset(d, out=rb))
+            # alternate the two layouts of the reset screens: env i's in row i, or - packed, what the vector env's
+            # autoreset uploads as one copy - the j-th reset env's in row j
+            packed = bool(step % 2)
+            assert np.array_equal(py.reset(d, out=ra, packed=packed), nv.reset(d, out=rb, packed=packed))
             assert np.array_equal(ra, rb)
+            rows = range(len(d)) if packed else d
+            assert all(ra[r].any() for r in rows) and not np.delete(ra, list(rows), axis=0).any()
     assert n_done >= 5
     py.close()
     nv.close()
