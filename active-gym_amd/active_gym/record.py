@@ -87,13 +87,15 @@ class Recorder:
         self._new_buffer()
         self._save(np.asarray(state, dtype=np.float64), done=False, info=info, rgb=rgb)
         if fovea is not None:
+            # key order as the reference's reset_record_buffer builds it: fov_size, [peripheral_res,] fov_loc [, fov_res]
+            # (fov_env.py:152-154, 253-256, 370-373)
             b = self.w.record_buffer
             b["fov_size"] = fovea.fov_size
+            if hasattr(fovea, "peripheral_res"):
+                b["peripheral_res"] = fovea.peripheral_res
             b["fov_loc"] = [info["fov_loc"]]
             if "fov_res" in info:
                 b["fov_res"] = [info["fov_res"]]
-            if hasattr(fovea, "peripheral_res"):
-                b["peripheral_res"] = fovea.peripheral_res
 
     def on_step(self, state, action, cum_reward, done, truncated, info, return_reward, fovea=None):
         rgb = self.w.env.render()

@@ -295,8 +295,8 @@ int upload_owned(agx_ctx *ctx, const T **dptr, const std::vector<T> &h) {
 bool has_fovea(const agx_config &c) { return c.kind != AGX_KIND_BASE; }
 
 size_t fixed_lds(const agx_config &c) {
-    // window image u8 [fh][4 * ((fw + 6) / 4)] (16-B padded) | ytab[oh] | H[fh][ow]   (the carve of fovea_fixed_body)
-    const size_t raw = ((size_t)c.fov_h * 4 * ((c.fov_w + 6) / 4) + 15) & ~(size_t)15;
+    // window rows u8 [fh][ow] (16-B padded) | ytab[oh] | H[fh][ow]   (the carve of fovea_fixed_body)
+    const size_t raw = ((size_t)c.fov_h * c.obs_w + 15) & ~(size_t)15;
     size_t b = raw;
     if (c.out_mode == AGX_OUT_RESIZE) b += (size_t)c.obs_h * sizeof(Tap) + (size_t)c.fov_h * c.obs_w * sizeof(float);
     return b;

@@ -27,8 +27,8 @@ __device__ __forceinline__ void store_obs(T4 *dst, const T4 &v) {
 // grid = (fs, N): workgroup (sl, n) owns PHYSICAL ring slot sl of env n, block = 256.
 // Prologue: the small state loads (action, fov_loc, head) and this thread's taps go out first; the scalar chain action ->
 // rint(clip(..)) -> (r, c) runs as soon as the state has arrived and moves to SGPRs; then ONLY the window of the slot is
-// fetched, for every MODE: its fh rows, and of each row the dword-aligned column span that holds [c, c + fw) (LDS image
-// u8 [fh][4 * ((fw + 6) / 4)]).  u8 -> float32 k/255 is unit_fast (3 FMAs, the correctly rounded quotient).
+// fetched, for every MODE: its fh rows (LDS image u8 [fh][ow]).  u8 -> float32 k/255 is unit_fast (3 FMAs, the correctly
+// rounded quotient).
 //   RESIZE: H[fh][ow] = horizontal lerp of the window rows (thread = fixed column x, rows y = yb+3k),
 //           then each output float4 is the vertical lerp of two ds_read_b128; stores are 16 B per
 //           lane, lane-linear, 1 KiB per wave at 1-KiB steps, nontemporal.
@@ -63,23 +63,23 @@ __device__ __forceinline__ void fovea_fixed_body(const G g, const FovParams &p, 
         const bool touched = clear || sl == wslot;
         if (p.phase != 3 && (p.phase == 1) == touched) return;   // phase 1 takes the untouched slots, phase 2 the rest
     }
-    // LDS carve: window image u8 [fh][wp] (16-B padded) | ytab[oh] | H[fh][ow]     (agx_api.hip: fixed_lds)
+    // LDS carve: window rows u8 [fh][ow] (16-B padded) | ytab[oh] | H[fh][ow]     (agx_api.hip: fixed_lds)
     unsigned char *raw = smem;
     const int fbytes = oh * ow;                                       // multiple of 4 (ow % 4 == 0)
-    const int raw_pad = (fh * 4 * ((fw + 6) >> 2) + 15) & ~15;
+    const int raw_pad = (fh * ow + 15) & ~15;
     Tap *ytab_s = reinterpret_cast<Tap *>(raw + raw_pad);
     float *H = reinterpret_cast<float *>(ytab_s + oh);
 
-    // ---- State first (vmcnt retires in order), then only the window of the slot: its fh rows, and of each row only the
-    // dword-aligned column span that holds [c, c + fw) - (fw + 6) / 4 dwords, 36 of the row's 84 bytes at 84 / 30.  Every
-    // resident workgroup of the launch starts with this burst: round 1 fetched the whole 7 KB frame at once to avoid the
-    // dependent round trip (3.6 us of a wave's 6.7 us life were that load chain), round 2 the fh full rows (2.5 KB: K2
-    // 23.1 -> 21.9 us), this form 1.1 KB.
+    // ---- State first (vmcnt retires in order), then only the fh window rows of the slot (2.5 KB of the 7 KB frame), for every
+    // MODE: every resident workgroup of the launch starts with this burst, and a third of the bytes returns sooner than the
+    // extra dependent round trip costs (round 1 fetched the whole frame to avoid that dependency: 3.6 us of a wave's 6.7 us
+    // life were the load chain; K2 23.1 -> 21.9 us).  Round 3 also built the narrower form - of each row only the
+    // dword-aligned column span that holds [c, c + fw), 1.1 KB - and measured a tie (23.4-23.5 us both, same box): the rows of
+    // a window are 84 bytes apart, so the span touches the same cache lines as the whole rows; not kept.
     const uint32_t *fsrc = reinterpret_cast<const uint32_t *>(p.ring + ((size_t)n * p.fs + sl) * (size_t)fbytes);
     int r, c, j;
     int4 xt = make_int4(0, 0, 0, 0);                                  // this thread's column taps {lo, aux, a, b}
-    const int span = (fw + 6) >> 2;                                   // dwords per window row in the LDS image
-    const int wp = span * 4;                                          // its row pitch in bytes
+    const int wp = ow;                                                // row pitch of the LDS image
     {
         const LocIn lin = load_loc_inputs(p, n);
         const int head = p.head[n] + head_fixup;
@@ -93,22 +93,13 @@ __device__ __forceinline__ void fovea_fixed_body(const G g, const FovParams &p, 
         c = __builtin_amdgcn_readfirstlane(c);
         j = sl - __builtin_amdgcn_readfirstlane(head);
         if (j < 0) j += p.fs;
-        const int ow4w = ow >> 2, fwords = fbytes >> 2;
-        const uint32_t *wsrc = fsrc + r * ow4w + (c >> 2);            // first dword of the window (wave-uniform)
-        const int wwords = fh * span;
-        const FastDiv dv_span(span);
-        // image dword i = (row i / span, column dword i % span); the last dword of the last row may lie past the frame's
-        // end (columns >= ow, never a tap): its index is clamped into the frame
-        const int wlimit = fwords - 1 - (r * ow4w + (c >> 2));
-        auto src_of = [&](int i) {
-            const int y = dv_span.div(i);
-            return min(y * ow4w + (i - y * span), wlimit);
-        };
-        constexpr int kW = 2;
+        const uint32_t *wsrc = fsrc + r * (ow >> 2);
+        const int wwords = (fh * ow) >> 2;
+        constexpr int kW = 3;
         uint32_t ww[kW];
 #pragma unroll
         for (int k = 0; k < kW; ++k) {
-            const uint32_t *q = wsrc + src_of(min(tid + k * kThreads, wwords - 1));
+            const uint32_t *q = wsrc + min(tid + k * kThreads, wwords - 1);
             ww[k] = COHERENT ? __hip_atomic_load(q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : *q;
         }
         if (sl == 0 && tid == 0) {
@@ -126,16 +117,14 @@ __device__ __forceinline__ void fovea_fixed_body(const G g, const FovParams &p, 
 #pragma unroll
         for (int k = 0; k < kW; ++k)
             if (tid + k * kThreads < wwords) reinterpret_cast<uint32_t *>(raw)[tid + k * kThreads] = ww[k];
-        for (int i = tid + kW * kThreads; i < wwords; i += kThreads) {
-            const uint32_t *q = wsrc + src_of(i);
-            reinterpret_cast<uint32_t *>(raw)[i] = COHERENT ? __hip_atomic_load(q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : *q;
-        }
+        for (int i = tid + kW * kThreads; i < wwords; i += kThreads)
+            reinterpret_cast<uint32_t *>(raw)[i] = COHERENT ? __hip_atomic_load(wsrc + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : wsrc[i];
         AGX_STAMP(1);
         __syncthreads();
         AGX_STAMP(2);
     }
     const int xcol = tid % ow, yb = tid / ow;                         // phase-C column / first row
-    const unsigned char *win = raw + (c & 3);                         // window origin inside the LDS image (pitch wp)
+    const unsigned char *win = raw + c;                               // window origin inside the LDS image (row r of the frame = row 0)
     if (MODE == AGX_OUT_RAW) {
         float *out = p.obs + ((size_t)n * p.fs + j) * (size_t)(fh * fw);
         for (int i = tid; i < fh * fw; i += kThreads) {
@@ -151,7 +140,7 @@ __device__ __forceinline__ void fovea_fixed_body(const G g, const FovParams &p, 
             const int row = q / ow4, x = (q - row * ow4) * 4;
             float v[4] = {0.f, 0.f, 0.f, 0.f};
             if (row >= r && row < r + fh && x + 3 >= c && x < c + fw) {
-                const uint32_t w = *reinterpret_cast<const uint32_t *>(raw + (row - r) * wp + (x - (c & ~3)));
+                const uint32_t w = *reinterpret_cast<const uint32_t *>(raw + (row - r) * wp + x);
 #pragma unroll
                 for (int k = 0; k < 4; ++k)
                     if (x + k >= c && x + k < c + fw) v[k] = unit_fast((float)((w >> (8 * k)) & 0xFF));

@@ -130,29 +130,25 @@ __global__ __launch_bounds__(kThreads) void k_fovea_flexible3(G g, Flex3Params t
         }
     }
     const bool squeeze = rh > fh;                                     // rows only, fov_env.py:286
-    // ---- ... then the part of this slot the window needs: rows [r, r + rh + 8) clipped to the frame (the 8 rows of slack are
-    // read with zero weights; what lies past the frame's end stays whatever the LDS held - bytes, hence finite as floats),
-    // and of each row only the dword-aligned column span that holds [c, c + rw).  On average a fifth of the 7 KB frame
-    // (round 2 fetched whole rows: half of it): the burst every resident workgroup of the launch starts with.
+    // ---- ... then the rows of this slot the window needs: [r, r + rh + 8) clipped to the frame (the 8 rows of slack are read
+    // with zero weights; what lies past the frame's end stays whatever the LDS held - bytes, hence finite as floats).  On
+    // average half of the 7 KB frame: the burst every resident workgroup starts with is halved.  (Round 3 built two further
+    // cuts, measured them on the same box against this form and kept neither: only the dword-aligned column span of each
+    // row - a fifth of the frame - 26.9-27.1 vs 26.2-26.4 us: rows are 84 bytes apart, the span touches the same cache lines and
+    // pays a division per dword; and the composed W taps requested only after the window had left its registers - 64
+    // VGPRs instead of 76, eight waves per SIMD instead of six - 26.7 us: their L2 round trip no longer hides under the
+    // window load.)
     const int wrows = min(rh + 8, oh - r);
-    const int span = ((c & 3) + rw + 3) >> 2;                         // dwords per image row (<= ow / 4)
-    const int wp = span * 4;                                          // image row pitch in bytes
-    const int wwords = wrows * span;
-    const int ow4s = ow >> 2;
-    const uint32_t *wsrc = fsrc + r * ow4s + (c >> 2);                // first dword of the window (wave-uniform)
-    const int wlimit = (fbytes >> 2) - 1 - (r * ow4s + (c >> 2));     // the slack may reach past the frame: clamped
-    const FastDiv dv_span(span);
-    auto src_of = [&](int i) {
-        const int y = dv_span.div(i);
-        return min(y * ow4s + (i - y * span), wlimit);
-    };
+    const int wp = ow;                                                // row pitch of the LDS image
+    const int wwords = (wrows * ow) >> 2;
+    const uint32_t *wsrc = fsrc + r * (ow >> 2);
     constexpr int kFW = 7;
     uint32_t fw_[kFW];
 #pragma unroll
     for (int k = 0; k < kFW; ++k)
-        if (k * kThreads < wwords) fw_[k] = wsrc[src_of(min(tid + k * kThreads, wwords - 1))];
+        if (k * kThreads < wwords) fw_[k] = wsrc[min(tid + k * kThreads, wwords - 1)];
 
-    // ---- the taps of the first passes, requested now (L2 hits; they land under the window load)
+    // ---- the taps this thread will use, requested now (L2 hits; they land under the window load)
     const int rstep = kThreads / ow;                                  // rows per sweep of the W passes (3 for ow = 84)
     const int xcol = tid % ow, yb = tid / ow;
     const int yf = tid >> 3, xl = tid & 7;                            // H-squeeze role
@@ -181,33 +177,34 @@ __global__ __launch_bounds__(kThreads) void k_fovea_flexible3(G g, Flex3Params t
     } else {
         xt = *reinterpret_cast<const int4 *>(t.wf + rw * ow + xcol);
     }
-    // ---- LDS image: the window (row r, column 4 (c / 4) of the frame is byte 0 of the image), the row taps
+    auto load_wc = [&]() {
+        if (squeeze) {
+            wlo = t.wc_lo[rw * ow + xcol];
+            const float4 *ws = reinterpret_cast<const float4 *>(t.wc_w + wc_off + xcol * Tw);
+            const float4 a0 = ws[0];
+            wc[0] = a0.x, wc[1] = a0.y, wc[2] = a0.z, wc[3] = a0.w;
+            if (Tw > 4) {
+                const float4 a1 = ws[1];
+                wc[4] = a1.x, wc[5] = a1.y, wc[6] = a1.z, wc[7] = a1.w;
+            }
+            if (Tw > 8) {
+                const float4 a2 = ws[2], a3 = ws[3];
+                wc[8] = a2.x, wc[9] = a2.y, wc[10] = a2.z, wc[11] = a2.w;
+                wc[12] = a3.x, wc[13] = a3.y, wc[14] = a3.z, wc[15] = a3.w;
+            }
+        }
+    };
+    load_wc();
+    // ---- LDS image: the window rows (row r of the frame is row 0 of the image), the row taps
 #pragma unroll
     for (int k = 0; k < kFW; ++k)
         if (tid + k * kThreads < wwords) reinterpret_cast<uint32_t *>(raw)[tid + k * kThreads] = fw_[k];
-    for (int i = tid + kFW * kThreads; i < wwords; i += kThreads) reinterpret_cast<uint32_t *>(raw)[i] = wsrc[src_of(i)];
+    for (int i = tid + kFW * kThreads; i < wwords; i += kThreads) reinterpret_cast<uint32_t *>(raw)[i] = wsrc[i];
     if (tid < oh) ytab_s[tid] = yt;
     for (int i = tid + kThreads; i < oh; i += kThreads) ytab_s[i] = t.hy[rh * oh + i];
-    // ---- the composed W taps are not needed before the second pass: requested only now, when the window's registers are
-    // free again (all of it up front took the kernel to 76 VGPRs = six waves per SIMD)
-    if (squeeze) {
-        wlo = t.wc_lo[rw * ow + xcol];
-        const float4 *ws = reinterpret_cast<const float4 *>(t.wc_w + wc_off + xcol * Tw);
-        const float4 a0 = ws[0];
-        wc[0] = a0.x, wc[1] = a0.y, wc[2] = a0.z, wc[3] = a0.w;
-        if (Tw > 4) {
-            const float4 a1 = ws[1];
-            wc[4] = a1.x, wc[5] = a1.y, wc[6] = a1.z, wc[7] = a1.w;
-        }
-        if (Tw > 8) {
-            const float4 a2 = ws[2], a3 = ws[3];
-            wc[8] = a2.x, wc[9] = a2.y, wc[10] = a2.z, wc[11] = a2.w;
-            wc[12] = a3.x, wc[13] = a3.y, wc[14] = a3.z, wc[15] = a3.w;
-        }
-    }
     __syncthreads();
 
-    const unsigned char *win = raw + (c & 3);                         // window origin inside the LDS image (pitch wp)
+    const unsigned char *win = raw + c;                               // window origin inside the LDS image
     const float *E;
     if (squeeze) {
         // ---- D = Hdwn . crop   (columns up to max(rw, Tw) so that every D element the W pass reads is finite)

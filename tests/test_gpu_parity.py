@@ -40,6 +40,15 @@ def test_native_library_is_loaded():
     assert lib.agx_abi_version() == 1
     maps = open("/proc/self/maps").read()
     assert "libagx.so" in maps
+    # ... and it is built from the sources in this tree (a stale .so travelling to the GPU box would make every test here
+    # a test of something else): agx_build_info() carries the hash build.py takes over the kernel and ABI sources
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("agx_build", os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))),
+                                                                            "active-gym_amd", "build.py"))
+    bld = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bld)
+    if not os.environ.get("AGX_LIB"):
+        assert nat.build_info().endswith(" src " + bld.source_hash()), (nat.build_info(), bld.source_hash())
 
 
 # ---------------------------------------------------------------- K0 / unit conversion
