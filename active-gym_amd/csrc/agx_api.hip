@@ -50,7 +50,7 @@ struct agx_ctx {
     FlexRawParams fr{};
     bool fr_ok = false;
     size_t fr_lds = 0;
-    int64_t *pack_local = nullptr;   // agx_fovea_flexible_packed: [N] block-local exclusive offsets, [ceil(N/1024)] block totals
+    int64_t *pack_local = nullptr;   // agx_fovea_flexible_packed: [N] block-local exclusive offsets, [ceil(N/256)] block totals
     int64_t *pack_block = nullptr;   // (both allocated in agx_create for flexible raw-crop contexts: no allocation in a step call)
     // K3 tuned form 3 (k_fovea_peripheral3)
     Per3Params p3{};

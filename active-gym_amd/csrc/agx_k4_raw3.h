@@ -14,9 +14,9 @@
 // AGX_OUT_RAW - the crop at the origin of a zeroed [oh][ow] frame (padded batch); AGX_OUT_MASK - pasted at (r, c).
 //
 // Packed layout: offsets[] is an exclusive scan of fs * rh * rw over the envs' NEW resolutions, so the state update runs
-// first, as k_flex_state_scan: grid = ceil(N / 1024) workgroups of 256 threads x 4 envs; each writes the env-local
-// exclusive offsets of its 1024 envs and its block total.  The crop launch then only reads the final state; a workgroup of
-// a later block adds the totals of the blocks before it (<= 63 values, one wave reduction).  Two launches, no allocation,
+// first, as k_flex_state_scan: grid = ceil(N / 256) workgroups, one env per thread; each writes the env-local exclusive
+// offsets of its 256 envs and its block total.  The crop launch then only reads the final state; a workgroup of a later
+// block adds the totals of the blocks before it (<= 255 values: four per lane and one wave reduction).  Two launches, no allocation,
 // any N <= 65,535.
 #pragma once
 #include "agx_fov_common.h"
@@ -26,7 +26,7 @@
 namespace agx {
 
 constexpr int kRawPacked = 100;
-constexpr int kScanEnvsPerBlock = 1024;
+constexpr int kScanEnvsPerBlock = kThreads;      // one env per thread of a 256-thread scan workgroup
 
 struct FlexRawParams {
     const int2 *wb_meta;      // [ow + 1]       {T, first float of that size's table in wb_w}, T in {4, 8, 16}
@@ -39,8 +39,8 @@ struct FlexRawParams {
     int32_t r0_bytes, r1_bytes;
     int32_t dp;               // pitch of D in floats (multiple of 8, >= ow)
     // packed form
-    const int64_t *local_off; // [N]  exclusive offset of env n inside its block of 1024 envs
-    const int64_t *block_tot; // [ceil(N / 1024)]
+    const int64_t *local_off; // [N]  exclusive offset of env n inside its scan block (kScanEnvsPerBlock envs)
+    const int64_t *block_tot; // [ceil(N / kScanEnvsPerBlock)]
     int64_t *offsets;         // [N + 1] out (written by the crop launch)
     int32_t n_envs;
 };
@@ -56,16 +56,13 @@ __global__ __launch_bounds__(kThreads) void k_flex_state_scan(FlexScanParams q) 
     __shared__ int64_t wave_tot[kThreads / 64];
     const FovParams &p = q.f;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int n0 = blockIdx.x * kScanEnvsPerBlock + 4 * tid;
-    int64_t s[4];
-#pragma unroll
-    for (int e = 0; e < 4; ++e) {
-        const int n = n0 + e;
-        s[e] = 0;
-        if (n >= q.n) continue;
+    const int n = blockIdx.x * kScanEnvsPerBlock + tid;
+    int64_t mine = 0;
+    if (n < q.n) {
         const LocIn lin = load_loc_inputs(p, n);
-        int rh = min(max(p.res_in[2 * n], 1), q.oh), rw = min(max(p.res_in[2 * n + 1], 1), q.ow), r, c;
+        const int2 res_old = *reinterpret_cast<const int2 *>(p.res_in + 2 * n);
         const int type = (p.action && p.action_type) ? p.action_type[n] : AGX_FOV_LOC;
+        int rh = min(max(res_old.x, 1), q.oh), rw = min(max(res_old.y, 1), q.ow), r, c;
         if (p.action && type == AGX_FOV_RES) {
             rh = clip_rint(action_value(p.action_dt, lin.w[0], lin.w[1]), 1.0, (double)q.oh);
             rw = clip_rint(action_value(p.action_dt, lin.w[2], lin.w[3]), 1.0, (double)q.ow);
@@ -78,9 +75,8 @@ __global__ __launch_bounds__(kThreads) void k_flex_state_scan(FlexScanParams q) 
         *reinterpret_cast<int2 *>(p.res_out + 2 * n) = make_int2(rh, rw);
         if (p.user_loc) *reinterpret_cast<int2 *>(p.user_loc + 2 * n) = make_int2(r, c);
         if (p.user_res) *reinterpret_cast<int2 *>(p.user_res + 2 * n) = make_int2(rh, rw);
-        s[e] = (int64_t)p.fs * rh * rw;
+        mine = (int64_t)p.fs * rh * rw;
     }
-    const int64_t mine = s[0] + s[1] + s[2] + s[3];
     int64_t incl = mine;                                        // inclusive scan over the wave
 #pragma unroll
     for (int d = 1; d < 64; d <<= 1) {
@@ -93,13 +89,8 @@ __global__ __launch_bounds__(kThreads) void k_flex_state_scan(FlexScanParams q) 
 #pragma unroll
     for (int w = 0; w < kThreads / 64; ++w)
         if (w < wave) before += wave_tot[w];
-    int64_t run = before + incl - mine;
-#pragma unroll
-    for (int e = 0; e < 4; ++e) {
-        if (n0 + e < q.n) q.local_off[n0 + e] = run;
-        run += s[e];
-    }
-    if (tid == kThreads - 1) q.block_tot[blockIdx.x] = run;
+    if (n < q.n) q.local_off[n] = before + incl - mine;
+    if (tid == kThreads - 1) q.block_tot[blockIdx.x] = before + incl;
 }
 
 // fallback of the packed form for geometries outside the raw3 plan: offsets[] from the two scan levels (grid = ceil((N+1)/256))
@@ -136,20 +127,29 @@ __global__ __launch_bounds__(kThreads) void k_fovea_flexible_raw3(G g, FlexRawPa
     int rh, rw, r, c, head;
     int64_t poff = 0;
     if (PACKED) {
-        const int2 rc = uniform_load_i32x2(reinterpret_cast<const int2 *>(p.loc_in) + n);
-        const int2 hw = uniform_load_i32x2(reinterpret_cast<const int2 *>(p.res_in) + n);
-        head = uniform_load_i32(p.head + n);
-        r = rc.x, c = rc.y, rh = hw.x, rw = hw.y;
+        // one batch of (wave-uniform) loads, one wait: final state, ring head, this env's block-local offset ...
+        const int2 rc = *(reinterpret_cast<const int2 *>(p.loc_in) + n);
+        const int2 hw = *(reinterpret_cast<const int2 *>(p.res_in) + n);
+        const int hd = p.head[n];
+        int64_t off = t.local_off[n];
+        // ... and the totals of the scan blocks before this env's (at most 255: four per lane, one wave reduction)
         const int b = n / kScanEnvsPerBlock;
-        if (b > 0) {                                            // totals of the blocks before this env's (<= 63)
-            int64_t v = (tid & 63) < b ? t.block_tot[tid & 63] : 0;
+        if (b > 0) {
+            int64_t v = 0;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const int i = (tid & 63) + 64 * k;
+                if (i < b) v += t.block_tot[i];
+            }
 #pragma unroll
             for (int d = 32; d >= 1; d >>= 1) v += __shfl_xor(v, d, 64);
-            poff = v;
+            off += v;
         }
-        poff += t.local_off[n];
-        poff = ((int64_t)__builtin_amdgcn_readfirstlane((int)(poff >> 32)) << 32) |
-               (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)poff);
+        r = __builtin_amdgcn_readfirstlane(rc.x), c = __builtin_amdgcn_readfirstlane(rc.y);
+        rh = __builtin_amdgcn_readfirstlane(hw.x), rw = __builtin_amdgcn_readfirstlane(hw.y);
+        head = __builtin_amdgcn_readfirstlane(hd);
+        poff = ((int64_t)__builtin_amdgcn_readfirstlane((int)(off >> 32)) << 32) |
+               (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)off);
         if (sl == 0 && tid == 0) {
             t.offsets[n] = poff;
             if (n == t.n_envs - 1) t.offsets[n + 1] = poff + (int64_t)p.fs * rh * rw;
@@ -192,35 +192,9 @@ __global__ __launch_bounds__(kThreads) void k_fovea_flexible_raw3(G g, FlexRawPa
     const int pr = OUT == AGX_OUT_MASK ? r : 0, pc = OUT == AGX_OUT_MASK ? c : 0;   // where the crop lands in a full frame
     const FastDiv dv_rw(rw);
 
-    if (!squeeze) {
-        // ---- the crop itself, exact k/255: straight from the ring (the window's bytes are read once)
-        const uint8_t *win = frame + r * ow + c;
-        if (PACKED) {
-            for (int i = tid; i < cnt; i += kThreads) {
-                const int y = dv_rw.div(i), x = i - y * rw;
-                pdst[i] = unit_fast((float)win[y * ow + x]);
-            }
-        } else {
-            for (int q = tid; q < oh * ow4; q += kThreads) {
-                const int row = q / ow4, x = (q - row * ow4) * 4;
-                const int y = row - pr;
-                float v[4] = {0.f, 0.f, 0.f, 0.f};
-                if (y >= 0 && y < rh) {
-#pragma unroll
-                    for (int k = 0; k < 4; ++k) {
-                        const int xx = x + k - pc;
-                        if (xx >= 0 && xx < rw) v[k] = unit_fast((float)win[y * ow + xx]);
-                    }
-                }
-                store_obs(&out4[q], make_float4(v[0], v[1], v[2], v[3]));
-            }
-        }
-        return;
-    }
-
-    // ---- squeeze path: window rows [r, r + rh + 8) clipped to the frame (slack rows are read with zero weights), and of each
-    // row the dword-aligned column span that holds [c, c + rw) (as k_fovea_flexible3 does)
-    const int wrows = min(rh + 8, oh - r);
+    // ---- the window -> LDS: rows [r, r + rh) (squeeze path: + 8 rows of slack, read with zero weights, clipped to the frame),
+    // of each row the dword-aligned column span that holds [c, c + rw); one round trip for the whole workgroup
+    const int wrows = squeeze ? min(rh + 8, oh - r) : rh;
     const int span = ((c & 3) + rw + 3) >> 2;
     const int wp = span * 4;
     const int wwords = wrows * span;
@@ -236,6 +210,37 @@ __global__ __launch_bounds__(kThreads) void k_fovea_flexible_raw3(G g, FlexRawPa
 #pragma unroll
     for (int k = 0; k < kFW; ++k)
         if (k * kThreads < wwords) fw_[k] = wsrc[src_of(min(tid + k * kThreads, wwords - 1))];
+    if (!squeeze) {
+        // ---- the crop itself, exact k/255
+#pragma unroll
+        for (int k = 0; k < kFW; ++k)
+            if (tid + k * kThreads < wwords) reinterpret_cast<uint32_t *>(raw)[tid + k * kThreads] = fw_[k];
+        for (int i = tid + kFW * kThreads; i < wwords; i += kThreads) reinterpret_cast<uint32_t *>(raw)[i] = wsrc[src_of(i)];
+        __syncthreads();
+        const unsigned char *win = raw + (c & 3);
+        if (PACKED) {
+            for (int i = tid; i < cnt; i += kThreads) {
+                const int y = dv_rw.div(i), x = i - y * rw;
+                pdst[i] = unit_fast((float)win[y * wp + x]);
+            }
+        } else {
+            for (int q = tid; q < oh * ow4; q += kThreads) {
+                const int row = q / ow4, x = (q - row * ow4) * 4;
+                const int y = row - pr;
+                float v[4] = {0.f, 0.f, 0.f, 0.f};
+                if (y >= 0 && y < rh) {
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) {
+                        const int xx = x + k - pc;
+                        if (xx >= 0 && xx < rw) v[k] = unit_fast((float)win[y * wp + xx]);
+                    }
+                }
+                store_obs(&out4[q], make_float4(v[0], v[1], v[2], v[3]));
+            }
+        }
+        return;
+    }
+
     const int rstep = kThreads / ow;
     const int xcol = tid % ow, yb = tid / ow;
     const int yf = tid >> 3, xl = tid & 7;

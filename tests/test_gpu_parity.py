@@ -877,7 +877,7 @@ def test_flexible_packed_equals_padded(dev, aa, generic, monkeypatch):
         monkeypatch.delenv(k_, raising=False)
     if generic:
         monkeypatch.setenv("AGX_FOVEA_GENERIC", "1")
-    N, fs = 37, 3
+    N, fs = (37, 3) if generic else (700, 3)        # 700 envs: three blocks of the two-level offset scan (256 envs each)
     kw = dict(num_envs=N, kind="flexible", obs_size=(84, 84), fov_size=(30, 30), frame_stack=fs, fov_init_loc=(3, 4),
               sensory_action_mode="absolute", antialias=aa)
     a_, b_ = _pipe(**kw), _pipe(**kw)
