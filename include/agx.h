@@ -230,7 +230,10 @@ AGX_API int agx_fovea_flexible(agx_ctx *ctx, const void *d_action, int action_dt
  *                               d_offsets[N] = total floats = sum_n fs * res_h[n] * res_w[n]
  *   d_packed  f32 [capacity_floats] out; an env whose crops would end past the capacity is not written
  *                               (d_offsets[N] > capacity_floats tells the caller; N * fs * obs_h * obs_w always fits)
- * Context: AGX_KIND_FLEXIBLE with AGX_OUT_RAW.  No mask: the layout of every env depends on every resolution. */
+ * Context: AGX_KIND_FLEXIBLE with AGX_OUT_RAW.  No mask: the layout of every env depends on every resolution.
+ * Two launches: the state update of every env + level 1 of an exclusive scan of the crop sizes (256 envs per workgroup,
+ * scratch owned by the context since agx_create - nothing is allocated here), then the crops, whose workgroups add the
+ * totals of the scan blocks before theirs and write d_offsets. */
 AGX_API int agx_fovea_flexible_packed(agx_ctx *ctx, const void *d_action, int action_dtype, const int32_t *d_action_type,
                                       float *d_packed, int64_t capacity_floats, int64_t *d_offsets, int32_t *d_fov_loc,
                                       int32_t *d_fov_res, void *stream);

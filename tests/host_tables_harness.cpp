@@ -6,6 +6,7 @@
 // Build: hipcc -std=c++17 -I include -I active-gym_amd/csrc tests/host_tables_harness.cpp -o <out>   (host code only)
 // Usage: harness oh ow fh fw antialias          (k_fovea_flexible3 tables) -> "max_err <e> cases <n>" | "unsupported"
 //        harness per oh ow ph pw antialias      (k_fovea_peripheral3 tables + unit_fast over all 256 values)
+//        harness raw oh ow fh fw antialias      (k_fovea_flexible_raw3 tables: raw-crop / mask-out / packed forms)
 #include <cstdio>
 #include <cstdlib>
 #include <random>
@@ -98,8 +99,94 @@ static int per_main(int argc, char **argv) {
     return 0;
 }
 
+
+// k_fovea_flexible_raw3 (agx_k4_raw3.h): the squeeze-and-expand-back chain of the raw-crop / mask-out / packed forms.
+// Replays the kernel on its LDS image of the window (rows [r, r + rh + 8) clipped to the frame, of each row the dword-aligned
+// column span holding [c, c + rw), a dword past the frame's end clamped to its last dword) with stale-LDS NaNs everywhere
+// else, and compares with  crop -> Resize(fov_size) -> Resize(fov_res)  (fov_env.py:276-287) in double.
+static int raw_main(int argc, char **argv) {
+    if (argc < 7) return 2;
+    agx_config c{};
+    c.obs_h = atoi(argv[2]); c.obs_w = atoi(argv[3]); c.fov_h = atoi(argv[4]); c.fov_w = atoi(argv[5]);
+    c.antialias = atoi(argv[6]);
+    c.out_mode = AGX_OUT_RAW;
+    const FlexRawHost h = build_flexraw(c);
+    if (!h.ok) { printf("unsupported\n"); return 0; }
+    const int oh = c.obs_h, ow = c.obs_w, fh = c.fov_h, fw = c.fov_w;
+    const bool aa = c.antialias != 0;
+    const int rstep = kThreads / ow, erows = (fh + rstep - 1) / rstep * rstep;
+    std::mt19937 rng(11);
+    double worst = 0;
+    long cases = 0;
+    std::vector<unsigned char> R0(h.r0_bytes);
+    std::vector<float> D((size_t)h.r1_bytes / 4), E((size_t)h.r0_bytes / 4);
+    for (int rh = fh + 1; rh <= oh; ++rh)
+        for (int rw = 1 + (rh * 5) % 3; rw <= ow; rw += 3) {
+            const int r = (int)(rng() % (unsigned)(oh - rh + 1)), cc = (int)(rng() % (unsigned)(ow - rw + 1));
+            std::vector<unsigned char> F((size_t)oh * ow);
+            for (auto &b : F) b = (unsigned char)(rng() & 0xFF);
+            for (auto &b : R0) b = (unsigned char)(rng() & 0xFF);
+            for (auto &v : D) v = NAN;
+            for (auto &v : E) v = NAN;
+            const int wrows = std::min(rh + 8, oh - r), span = ((cc & 3) + rw + 3) >> 2, wp = span * 4;
+            if ((size_t)wrows * wp > (size_t)h.r0_bytes || wp > ow) { printf("image too large rh=%d rw=%d\n", rh, rw); return 1; }
+            for (int i = 0; i < wrows * span; ++i) {
+                const int y = i / span, q = i - y * span;
+                const int src = std::min((r + y) * (ow / 4) + (cc >> 2) + q, oh * ow / 4 - 1);
+                memcpy(&R0[(size_t)i * 4], &F[(size_t)src * 4], 4);
+            }
+            const unsigned char *win = R0.data() + (cc & 3);
+            auto in_r0 = [&](const unsigned char *p) { return p >= R0.data() && p < R0.data() + h.r0_bytes; };
+            const int Tw = h.wb_meta[rw].x, Th = h.hd_meta[rh].x;
+            const int kmax = (std::max(rw, Tw) + 7) >> 3;
+            if (8 * kmax > h.dp) { printf("D pitch too small rw=%d\n", rw); return 1; }
+            for (int yf = 0; yf < fh; ++yf)
+                for (int x = 0; x < 8 * kmax; ++x) {
+                    const int lo = h.hd_lo[(size_t)rh * fh + yf];
+                    const float *w = &h.hd_w[h.hd_meta[rh].y + (size_t)yf * Th];
+                    float acc = 0.f;
+                    for (int q = 0; q < Th; ++q) {
+                        const unsigned char *p = win + (lo + q) * wp + x;
+                        if (!in_r0(p)) { printf("raw read outside R0 rh=%d rw=%d\n", rh, rw); return 1; }
+                        acc = fmaf(w[q], (float)*p, acc);
+                    }
+                    D[(size_t)yf * h.dp + x] = acc;
+                }
+            if (erows * ow * 4 > h.r0_bytes) { printf("E does not fit R0\n"); return 1; }
+            for (int y = 0; y < fh; ++y)
+                for (int x = 0; x < ow; ++x) {
+                    const int lo = h.wb_lo[(size_t)rw * ow + x];
+                    const float *w = &h.wb_w[h.wb_meta[rw].y + (size_t)x * Tw];
+                    if (lo < 0 || lo + Tw > 8 * kmax) { printf("D read outside the written columns rw=%d x=%d\n", rw, x); return 1; }
+                    float acc = 0.f;
+                    for (int q = 0; q < Tw; ++q) acc = fmaf(w[q], D[(size_t)y * h.dp + lo + q], acc);
+                    E[(size_t)y * ow + x] = acc;
+                }
+            std::vector<double> crop((size_t)rh * rw);
+            for (int y = 0; y < rh; ++y)
+                for (int x = 0; x < rw; ++x) {
+                    if (win[y * wp + x] != F[(size_t)(r + y) * ow + cc + x]) { printf("image != frame window rh=%d rw=%d\n", rh, rw); return 1; }
+                    crop[(size_t)y * rw + x] = (double)F[(size_t)(r + y) * ow + cc + x] / 255.0;
+                }
+            const std::vector<double> ref = resize(resize(crop, rh, rw, fh, fw, aa), fh, fw, rh, rw, aa);
+            for (int y = 0; y < rh; ++y) {
+                const Tap tp = h.hb[(size_t)rh * oh + y];
+                if (tp.lo < 0 || tp.aux >= fh) { printf("row tap rh=%d y=%d\n", rh, y); return 1; }
+                for (int x = 0; x < rw; ++x) {
+                    const float o = fmaf(tp.b, E[(size_t)tp.aux * ow + x], tp.a * E[(size_t)tp.lo * ow + x]);
+                    const double err = std::fabs((double)o - ref[(size_t)y * rw + x]);
+                    if (!(err <= worst)) worst = err;      // NaN-propagating max
+                }
+            }
+            ++cases;
+        }
+    printf("max_err %.3e cases %ld lds %zu\n", worst, cases, h.lds(c));
+    return 0;
+}
+
 int main(int argc, char **argv) {
     if (argc > 1 && !strcmp(argv[1], "per")) return per_main(argc, argv);
+    if (argc > 1 && !strcmp(argv[1], "raw")) return raw_main(argc, argv);
     if (argc < 6) return 2;
     agx_config c{};
     c.obs_h = atoi(argv[1]); c.obs_w = atoi(argv[2]); c.fov_h = atoi(argv[3]); c.fov_w = atoi(argv[4]);

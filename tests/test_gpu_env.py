@@ -362,6 +362,33 @@ def test_record_buffers_match_reference_run(kind, factory, tmp_path):
     env.close()
 
 
+@pytest.mark.parametrize("kind", ["base", "fixed"])
+def test_reset_does_not_overwrite_the_observation_the_caller_holds(kind):
+    """Device outputs are double-buffered: an observation returned by step() stays valid until the step after next.  reset()
+    and reset_envs() take the next buffer too - the terminal observation a caller still holds must not turn into the reset
+    observation under its hands (and the reset observation must not alias it)."""
+    from active_gym import AtariVecEnv
+    N = 6
+    args = _args(fov_size=(30, 30), fov_init_loc=(0, 0), sensory_action_mode="absolute", resize_to_full=True, device="cuda:0")
+    env = AtariVecEnv(args, N, kind=kind, autoreset=False)
+    env.reset()
+    act = np.zeros(N, np.int64) if kind == "base" else {"motor_action": np.zeros(N, np.int64), "sensory_action": np.full((N, 2), 11.0)}
+    env.step(act)
+    held, *_ = env.step(act)
+    snap = held.clone()
+    robs, _ = env.reset_envs([1, 4])
+    assert robs.data_ptr() != held.data_ptr()
+    assert torch.equal(held, snap), "reset_envs() rewrote the observation returned by the previous step()"
+    for i in (0, 2, 3, 5):                                   # envs that were not reset keep their observation
+        assert torch.equal(robs[i], snap[i])
+    assert not torch.equal(robs[1], snap[1])
+    held2, *_ = env.step(act)
+    snap2 = held2.clone()
+    robs2, _ = env.reset()
+    assert robs2.data_ptr() != held2.data_ptr() and torch.equal(held2, snap2)
+    env.close()
+
+
 def test_bench_contract_json():
     """bench.py prints ONE JSON line with the driver's contract fields (small, quick configuration)."""
     import json, os, subprocess, sys

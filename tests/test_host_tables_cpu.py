@@ -46,6 +46,15 @@ def test_peripheral3_tables_reproduce_squeeze_expand(harness, geom, aa):
     assert float(out.split()[1]) <= 2e-6, out
 
 
+@pytest.mark.parametrize("geom_aa", [(84, 84, 30, 30, 0), (84, 84, 30, 30, 1), (64, 48, 20, 12, 1), (36, 40, 7, 11, 0), (48, 40, 20, 24, 1)])
+def test_flexible_raw3_tables_reproduce_the_squeeze_and_back_chain(harness, geom_aa):
+    """k_fovea_flexible_raw3 (raw-crop / mask-out / packed forms): composed (Wbck Wdwn), Hdwn and Hbck tables against
+    crop -> Resize(fov_size) -> Resize(fov_res) in double, incl. the LDS image's index rules."""
+    out = _run(harness, "raw", *geom_aa)
+    assert out.startswith("max_err"), out
+    assert float(out.split()[1]) <= 2e-6, out
+
+
 def test_geometries_outside_the_plan_are_reported(harness):
     assert _run(harness, 128, 128, 31, 9, 1) == "unsupported"          # > 16 composed taps: k_fovea_flexible2 runs
     assert _run(harness, "per", 84, 84, 5, 5, 1) == "unsupported"      # > 16 squeeze taps: k_fovea_peripheral2 runs

@@ -107,6 +107,9 @@ def one_case(k):
     orcs = [orc() for _ in range(N)]
     for o in orcs:
         o.reset(np.zeros((fs, oh, ow)))
+    # flexible raw crops: every other case goes through the packed ragged entry point (agx_fovea_flexible_packed)
+    packed_case = kind == "flexible" and out == "raw" and rng.random() < 0.5
+    cfg["packed"] = packed_case
     for step in range(4):
         st = rng.integers(0, 256, (N, fs, oh, ow), dtype=np.uint8)
         p.set_stack_u8(t(st))
@@ -114,7 +117,16 @@ def one_case(k):
         if kind == "flexible":
             a = np.where(types[:, None] == 1, np.stack([rng.integers(1, oh + 1, N), rng.integers(1, ow + 1, N)], 1),
                          np.stack([rng.integers(-5, oh + 5, N), rng.integers(-5, ow + 5, N)], 1)).astype(np.int64)
-            r = p.fovea(t(a), action_type=t(types))
+            if packed_case:
+                flat, off, loc_t, res_t = p.fovea_packed(t(a), action_type=t(types))
+                flat, off, res_n = flat.cpu().numpy(), off.cpu().numpy(), res_t.cpu().numpy()
+                assert off[0] == 0 and np.array_equal(np.diff(off), fs * res_n[:, 0].astype(np.int64) * res_n[:, 1]), (cfg, step)
+                pad = np.zeros((N, fs, oh, ow), np.float32)
+                for i in range(N):
+                    pad[i, :, :res_n[i, 0], :res_n[i, 1]] = flat[off[i]:off[i + 1]].reshape(fs, res_n[i, 0], res_n[i, 1])
+                r = (torch.from_numpy(pad), loc_t, res_t)
+            else:
+                r = p.fovea(t(a), action_type=t(types))
         else:
             lo, hi = (-6.0, max(oh, ow) + 6.0) if mode == "absolute" else (-12.0, 12.0)
             a = rng.uniform(lo, hi, (N, 2))
