@@ -207,7 +207,6 @@ class DMCVecEnv(AtariVecEnv):
         self._h_cmd = torch.empty((self.num_envs,), dtype=torch.uint8, pin_memory=True)
         self._d_cmd = torch.empty((self.num_envs,), dtype=torch.uint8, device=self.device)
         self._ev_copy = torch.cuda.Event()
-        self._ev_rcopy = torch.cuda.Event()
         self._alloc_reset_buffers()
         self.runner = DMCHostRunner(args, self.num_envs, self._h_frames.numpy(), workers=getattr(args, "num_workers", None),
                                     env_offset=env_offset)
@@ -219,11 +218,11 @@ class DMCVecEnv(AtariVecEnv):
     def _motor_space(self):
         return Box(low=-1.0, high=1.0, shape=(self.runner.action_dim,), dtype=np.float32)      # dmc_env.py:112-117
 
-    def _ingest(self):
-        self.pipe.ingest_rgb(self._d_frames, self._d_cmd, self._gray_mode)
+    def _ingest(self, cmd=None):
+        self.pipe.ingest_rgb(self._d_frames, self._d_cmd if cmd is None else cmd, self._gray_mode)
 
-    def _h_reset_rows(self):
-        return self._h_rframes
+    def _h_reset_rows(self, buf=None):
+        return self._h_rframes if buf is None else buf
 
     def _d_reset_target(self):
         return self._d_frames

@@ -164,11 +164,12 @@ class AtariVecEnv:
     def _motor_space(self):
         return Discrete(self.runner.num_actions)
 
-    def _ingest(self):
+    def _ingest(self, cmd=None):
+        cmd = self._d_cmd if cmd is None else cmd
         if self._gray:
-            self.pipe.ingest_gray_raw(self._d_frames, self._d_cmd)
+            self.pipe.ingest_gray_raw(self._d_frames, cmd)
         else:
-            self.pipe.ingest(self._d_frames, self._d_cmd)
+            self.pipe.ingest(self._d_frames, cmd)
 
     def _extra_info(self, info):
         return info
@@ -190,16 +191,27 @@ class AtariVecEnv:
                         "ev": torch.cuda.Event()} for _ in range(nstage)]
         self._stage_i = 0
         self._h_frames = self._stage[0]["frames"]
-        self._d_frames = torch.empty(shape, dtype=torch.uint8, device=self.device)
+        # Device side.  With device outputs (no synchronisation inside step()) the step screens are double-buffered on the
+        # device too and travel on a COPY STREAM of their own: the H2D copy of step t+1 then runs under the kernels (and the
+        # autoreset pass) of step t instead of queueing behind them on the one stream - on a PCIe-bound step that is the
+        # difference between 87 % and ~95 % of the link.  Two events per buffer order the streams: `copied` (copy stream ->
+        # the kernels wait for their screens) and `free` (launch stream -> the copy that overwrites a buffer waits for the
+        # kernels that read it two steps earlier).  NumPy outputs synchronise every step anyway: one buffer, one stream.
+        ndev = 1 if self._numpy_out else 2
+        self._dsets = [{"frames": torch.empty(shape, dtype=torch.uint8, device=self.device),
+                        "cmd": torch.empty((self.num_envs,), dtype=torch.uint8, device=self.device),
+                        "free": torch.cuda.Event()} for _ in range(ndev)]
+        self._dset_i = 0
+        self._copy_stream = torch.cuda.Stream(device=self.device) if ndev > 1 else None
+        self._d_frames = self._dsets[0]["frames"]
         # reset screens get their own pinned buffer: the autoreset inside step() must not overwrite step
         # screens whose asynchronous H2D copy may still be in flight
         self._h_rframes = torch.empty((self.num_envs, 1, nat.RAW_H, nat.RAW_W) + px, dtype=torch.uint8, pin_memory=True)
         self._h_rcmd = torch.empty((self.num_envs,), dtype=torch.uint8, pin_memory=True)
         self._alloc_reset_buffers()
         self._ev_copy = self._stage[0]["ev"]
-        self._ev_rcopy = torch.cuda.Event()
         self._h_cmd = self._stage[0]["cmd"]
-        self._d_cmd = torch.empty((self.num_envs,), dtype=torch.uint8, device=self.device)
+        self._d_cmd = self._dsets[0]["cmd"]
         src = getattr(args, "frame_source", "ale")
         if isinstance(src, str) and src.startswith("native"):
             # C++ thread-per-core runner (libagx_runner.so): "native" = built-in scripted emulator,
@@ -215,18 +227,27 @@ class AtariVecEnv:
                                           env_offset=env_offset, noop_per_env=self._noop_per_env)
 
     def _alloc_reset_buffers(self):
-        # resets of a subset of the envs (the autoreset inside step()): the runner writes their screens PACKED into the first
-        # K rows of _h_rframes; one contiguous H2D copy into _d_rframes, one index_copy_ into slot 0 of the step screens.  The
-        # env indices and the done mask travel through pinned buffers too (a pageable .to(device) is a synchronous copy).
+        """Staging for resets of a SUBSET of the envs (the autoreset inside step(), reset_envs()).  The runner writes the K reset
+        screens PACKED into the first K rows of a pinned buffer: one contiguous H2D copy into _d_rframes, one index_copy_ into
+        slot 0 of the step screens.  Env indices, command bytes and the done mask travel together in one small pinned buffer
+        (one copy; a pageable .to(device) would be a synchronous one).  TWO pinned sets, used alternately: the set a reset
+        writes was last read by the copies of the reset before the previous one - waiting on the previous reset's event
+        instead would wait for that whole step's H2D copy and kernels, i.e. serialise the host with the GPU."""
+        n = self.num_envs
+        self._rsets = [{"frames": self._h_rframes if k == 0 else torch.empty_like(self._h_rframes).pin_memory(),
+                        "meta": torch.empty((10 * n,), dtype=torch.uint8, pin_memory=True),        # idx i64 [N] | cmd [N] | mask [N]
+                        "ev": torch.cuda.Event()} for k in range(2)]
+        self._rset_i = 0
+        self._rfree = torch.cuda.Event()        # launch stream: the kernels of the last partial reset have read the device-side staging
         self._d_rframes = None                  # allocated at the first partial reset
-        self._h_ridx = torch.empty((self.num_envs,), dtype=torch.int64, pin_memory=True)
-        self._d_ridx = torch.empty((self.num_envs,), dtype=torch.int64, device=self.device)
-        self._h_rmask = torch.empty((self.num_envs,), dtype=torch.uint8, pin_memory=True)
-        self._d_rmask = torch.empty((self.num_envs,), dtype=torch.uint8, device=self.device)
+        self._d_rmeta = torch.empty((10 * n,), dtype=torch.uint8, device=self.device)
+        self._d_ridx = self._d_rmeta[:8 * n].view(torch.int64)
+        self._d_rcmd = self._d_rmeta[8 * n:9 * n]
+        self._d_rmask = self._d_rmeta[9 * n:]
 
-    def _h_reset_rows(self):
+    def _h_reset_rows(self, buf=None):
         """Pinned reset screens, one row per env (Atari: slot 0 of a [N, 1, ...] buffer)."""
-        return self._h_rframes[:, 0]
+        return (self._h_rframes if buf is None else buf)[:, 0]
 
     def _d_reset_target(self):
         """Where a reset screen lands on the device: slot 0 of the env's step screens."""
@@ -252,42 +273,80 @@ class AtariVecEnv:
         return self.pipe.fov_state()[1].cpu().numpy()
 
     def _upload(self, cmd: np.ndarray):
-        """Asynchronous H2D of the step screens and the command bytes (pinned -> HBM, current stream)."""
+        """Asynchronous H2D of the step screens and the command bytes (pinned -> HBM): on the copy stream when there is one
+        (device outputs), ordered against the launch stream by events; on the current stream otherwise."""
         self._h_cmd.numpy()[:] = cmd
-        self._d_cmd.copy_(self._h_cmd, non_blocking=True)
-        self._d_frames.copy_(self._h_frames, non_blocking=True)
-        self._ev_copy.record(torch.cuda.current_stream(self.device))
+        cur = torch.cuda.current_stream(self.device)
+        cs = getattr(self, "_copy_stream", None)
+        if cs is None:
+            self._d_cmd.copy_(self._h_cmd, non_blocking=True)
+            self._d_frames.copy_(self._h_frames, non_blocking=True)
+            self._ev_copy.record(cur)
+            return
+        cs.wait_event(self._dsets[self._dset_i]["free"])        # the kernels that read this device buffer two steps ago
+        with torch.cuda.stream(cs):
+            self._d_cmd.copy_(self._h_cmd, non_blocking=True)
+            self._d_frames.copy_(self._h_frames, non_blocking=True)
+            self._ev_copy.record(cs)
+        cur.wait_event(self._ev_copy)
+
+    def _next_dset(self):
+        ds = getattr(self, "_dsets", None)
+        if ds is not None and len(ds) > 1:
+            self._dset_i ^= 1
+            self._d_frames, self._d_cmd = ds[self._dset_i]["frames"], ds[self._dset_i]["cmd"]
+
+    def _release_dset(self):
+        """Called when the last kernel that reads the current device screens has been enqueued."""
+        ds = getattr(self, "_dsets", None)
+        if ds is not None and len(ds) > 1:
+            cur = torch.cuda.current_stream(self.device)
+            ds[self._dset_i]["free"].record(cur)
+            self._rfree.record(cur)
 
     def _reset_subset(self, idx):
-        """runner.reset of the envs in `idx` + H2D of their screens and command bytes: the runner packs the K reset screens into
-        the first K rows of the pinned reset buffer, which cross PCIe as ONE copy and land in slot 0 of their envs' step screens
-        through one index_copy_ (round 2: one copy per done env).  Returns the done mask as a device tensor."""
+        """runner.reset of the envs in `idx` + H2D of their screens, command bytes, indices and mask (see _alloc_reset_buffers).
+        Returns (done mask, env indices) as device tensors; the command bytes of this pass are in self._d_rcmd."""
         idx = np.asarray(idx, dtype=np.int64)
-        k = len(idx)
-        self._ev_rcopy.synchronize()            # the previous partial reset has left the pinned reset buffers
-        cmd = self.runner.reset(idx, out=self._h_rframes.numpy(), packed=True)
-        self._h_rcmd.numpy()[:] = cmd
-        self._h_ridx.numpy()[:k] = idx
-        m = self._h_rmask.numpy()
+        k, n = len(idx), self.num_envs
+        self._rset_i ^= 1
+        st = self._rsets[self._rset_i]
+        st["ev"].synchronize()                  # the reset before the previous one has left this pinned set
+        cmd = self.runner.reset(idx, out=st["frames"].numpy(), packed=True)
+        meta = st["meta"].numpy()
+        meta[:8 * n].view(np.int64)[:k] = idx
+        meta[8 * n:9 * n] = cmd
+        m = meta[9 * n:]
         m[:] = 0
         m[idx] = 1
-        rows = self._h_reset_rows()
+        rows = self._h_reset_rows(st["frames"])
         if self._d_rframes is None:
             self._d_rframes = torch.empty(rows.shape, dtype=torch.uint8, device=self.device)
-        self._d_cmd.copy_(self._h_rcmd, non_blocking=True)
-        self._d_ridx[:k].copy_(self._h_ridx[:k], non_blocking=True)
-        self._d_rmask.copy_(self._h_rmask, non_blocking=True)
-        self._d_rframes[:k].copy_(rows[:k], non_blocking=True)
+        cur = torch.cuda.current_stream(self.device)
+        cs = getattr(self, "_copy_stream", None)
+        if cs is None:
+            self._d_rmeta.copy_(st["meta"], non_blocking=True)
+            self._d_rframes[:k].copy_(rows[:k], non_blocking=True)
+            st["ev"].record(cur)
+        else:
+            # on the COPY stream, i.e. queued between this step's screens and the next step's: a small copy issued on the launch
+            # stream would reach the DMA engine behind the next step's 200 MB copy and stall this step's reset kernels (and
+            # everything ordered after them) for a whole copy time - measured: 5.1 ms per RGB step instead of 4.1
+            cs.wait_event(self._rfree)                           # the previous reset's index_copy_ has read _d_rframes / _d_rmeta
+            with torch.cuda.stream(cs):
+                self._d_rmeta.copy_(st["meta"], non_blocking=True)
+                self._d_rframes[:k].copy_(rows[:k], non_blocking=True)
+                st["ev"].record(cs)
+            cur.wait_event(st["ev"])
         self._d_reset_target().index_copy_(0, self._d_ridx[:k], self._d_rframes[:k])
-        self._ev_rcopy.record(torch.cuda.current_stream(self.device))
-        return self._d_rmask
+        return self._d_rmask, self._d_ridx[:k]
 
     def _upload_reset_all(self, cmd: np.ndarray):
         """H2D of every env's reset screen (slot 0 only: one strided copy) and the command bytes."""
         self._h_rcmd.numpy()[:] = cmd
         self._d_cmd.copy_(self._h_rcmd, non_blocking=True)
         self._d_reset_target().copy_(self._h_reset_rows(), non_blocking=True)
-        self._ev_rcopy.record(torch.cuda.current_stream(self.device))
+        self._rsets[0]["ev"].record(torch.cuda.current_stream(self.device))
 
     def _as_device_action(self, a, cols):
         if isinstance(a, torch.Tensor):
@@ -379,7 +438,8 @@ class AtariVecEnv:
         for st in getattr(self, "_stage", []):
             st["ev"].synchronize()
         self._ev_copy.synchronize()
-        self._ev_rcopy.synchronize()
+        for rs in self._rsets:
+            rs["ev"].synchronize()
         cmd = self.runner.reset(out=self._h_rframes.numpy())
         self._upload_reset_all(cmd)
         self._ingest()
@@ -391,6 +451,7 @@ class AtariVecEnv:
         # next) must not be overwritten by the reset observation
         self._next_obs_buffer()
         obs = self._observe()
+        self._release_dset()
         self._was_reset = True
         return self._ret_obs(obs), self._with_masks(self._info(np.zeros(self.num_envs)), self.num_envs)
 
@@ -409,6 +470,7 @@ class AtariVecEnv:
         if isinstance(motor, torch.Tensor):
             motor = motor.detach().cpu().numpy()
         self._next_stage()                      # the other pinned set; waits only for the copy issued from it two steps ago
+        self._next_dset()                       # the other device screen buffer
         self._next_obs_buffer()
         chunk = int(getattr(self.args, "h2d_chunk_envs", 0) or 0)
         if chunk > 0 and hasattr(self.runner, "step_begin"):
@@ -434,24 +496,25 @@ class AtariVecEnv:
         infos = self._with_masks(info, n)
         if self.autoreset and done.any():
             idx = np.nonzero(done)[0]
+            # env.reset() of the done envs inside the same step (SyncVectorEnv, gymnasium<1.0).  Host first (emulators, pinned
+            # staging), then ONE batch of device work: uploads, the gathers of the terminal observations / infos (the kernels
+            # below overwrite them), ingest of the reset screens, masked re-observation.
+            mask, d_idx = self._reset_subset(idx)
             final_obs = np.empty(n, dtype=object)
             final_info = np.empty(n, dtype=object)
             if self._ragged_packed:
                 cur = self._ret_obs(obs)
                 fo = [cur[i].copy() if isinstance(cur[i], np.ndarray) else cur[i].clone() for i in idx]
             else:
-                self._ev_rcopy.synchronize()
-                self._h_ridx.numpy()[:len(idx)] = idx
-                self._d_ridx[:len(idx)].copy_(self._h_ridx[:len(idx)], non_blocking=True)
-                fo = self._out(obs.index_select(0, self._d_ridx[:len(idx)]))
+                fo = self._out(obs.index_select(0, d_idx))
+            # device-tensor info entries (fov_loc / fov_res with device outputs): one gather per key, rows handed out as views
+            gathered = {key: val.index_select(0, d_idx) for key, val in info.items() if isinstance(val, torch.Tensor)}
             for k, i in enumerate(idx):
                 final_obs[i] = fo[k]
-                final_info[i] = {key: (val[i].copy() if isinstance(val[i], np.ndarray) else
-                                       (val[i].clone() if isinstance(val[i], torch.Tensor) else val[i]))
+                final_info[i] = {key: (gathered[key][k] if key in gathered else
+                                       (val[i].copy() if isinstance(val[i], np.ndarray) else val[i]))
                                  for key, val in info.items()}
-            # env.reset() of the done envs inside the same step (SyncVectorEnv, gymnasium<1.0)
-            mask = self._reset_subset(idx)
-            self._ingest()
+            self._ingest(self._d_rcmd)
             self.cumulative_reward[idx] = 0
             self.ep_len[idx] = 0
             if self.kind == "base":
@@ -469,14 +532,15 @@ class AtariVecEnv:
             infos["_final_observation"] = done.copy()
             infos["final_info"] = final_info
             infos["_final_info"] = done.copy()
+        self._release_dset()
         return self._ret_obs(obs), reward, done, truncated, infos
 
     def reset_envs(self, idx):
         """Reset only the envs in `idx` (what a caller without autoreset does after `done`)."""
         idx = [int(i) for i in idx]
         n = self.num_envs
-        mask = self._reset_subset(idx)
-        self._ingest()
+        mask, _ = self._reset_subset(idx)
+        self._ingest(self._d_rcmd)
         self.cumulative_reward[idx] = 0
         self.ep_len[idx] = 0
         # a fresh output buffer, as in reset(): the terminal observation the caller holds from step() stays untouched
@@ -488,6 +552,7 @@ class AtariVecEnv:
         else:
             self.pipe.fovea_reset(mask)
             obs = self._observe(None, None, mask=mask)
+        self._release_dset()
         self._was_reset = True
         return self._ret_obs(obs), self._with_masks(self._info(np.zeros(n)), n)
 
