@@ -1263,7 +1263,8 @@ int agx_fovea_flexible(agx_ctx *ctx, const void *d_action, int action_dtype, con
             fam[k]->meta = ctx->flex_meta[k];
         }
         g.oh = c.obs_h; g.ow = c.obs_w; g.fh = c.fov_h; g.fw = c.fov_w;
-        AGX_LAUNCH(1, k_fovea_flexible2, dim3(c.frame_stack, c.num_envs), dim3(kThreads), lds2, S(stream), g, p);
+        if (c.out_mode == AGX_OUT_RESIZE) AGX_LAUNCH(1, k_fovea_flexible2<true>, dim3(c.frame_stack, c.num_envs), dim3(kThreads), lds2, S(stream), g, p);
+        else AGX_LAUNCH(1, k_fovea_flexible2<false>, dim3(c.frame_stack, c.num_envs), dim3(kThreads), lds2, S(stream), g, p);
     } else {
         hipLaunchKernelGGL((k_fovea_generic<AGX_KIND_FLEXIBLE>), dim3(c.frame_stack, c.num_envs), dim3(kThreads),
                            generic_lds(c), S(stream), gr, p);
@@ -1332,7 +1333,7 @@ int agx_fovea_flexible_packed(agx_ctx *ctx, const void *d_action, int action_dty
             fam[k]->meta = ctx->flex_meta[k];
         }
         fp.oh = c.obs_h; fp.ow = c.obs_w; fp.fh = c.fov_h; fp.fw = c.fov_w;
-        AGX_LAUNCH(1, k_fovea_flexible2, dim3(c.frame_stack, c.num_envs), dim3(kThreads), lds2, S(stream), fp, p);
+        AGX_LAUNCH(1, k_fovea_flexible2<false>, dim3(c.frame_stack, c.num_envs), dim3(kThreads), lds2, S(stream), fp, p);
     } else {
         hipLaunchKernelGGL((k_fovea_generic<AGX_KIND_FLEXIBLE>), dim3(c.frame_stack, c.num_envs), dim3(kThreads),
                            generic_lds(c), S(stream), gr, p);

@@ -138,68 +138,6 @@ __device__ __forceinline__ void stage_window(const uint8_t *frame, int ow, int r
 }
 
 
-// ---------------------------------------------------------------------------------------------
-// Flexible env, packed ragged output: the state update of FlexibleFovealEnv._fov_step (fov_env.py:300-324) as a
-// launch of its own - the packed layout needs every env's NEW resolution before any crop can be placed - followed by
-// an exclusive scan of the crop sizes fs * rh * rw.  grid = ceil(N / 256), block = 256.
-// ---------------------------------------------------------------------------------------------
-struct FlexStateParams {
-    FovParams f;
-    int64_t *sizes;       // [N] out: fs * rh * rw
-    int32_t n, oh, ow;
-};
-__global__ __launch_bounds__(kThreads) void k_flex_state(FlexStateParams q) {
-    const int n = blockIdx.x * kThreads + threadIdx.x;
-    if (n >= q.n) return;
-    const FovParams &p = q.f;
-    const LocIn lin = load_loc_inputs(p, n);
-    int rh = min(max(p.res_in[2 * n], 1), q.oh), rw = min(max(p.res_in[2 * n + 1], 1), q.ow), r, c;
-    const int type = (p.action && p.action_type) ? p.action_type[n] : AGX_FOV_LOC;
-    if (p.action && type == AGX_FOV_RES) {
-        rh = clip_rint(action_value(p.action_dt, lin.w[0], lin.w[1]), 1.0, (double)q.oh);
-        rw = clip_rint(action_value(p.action_dt, lin.w[2], lin.w[3]), 1.0, (double)q.ow);
-        r = clip_rint((double)lin.r, 0.0, (double)(q.oh - rh));
-        c = clip_rint((double)lin.c, 0.0, (double)(q.ow - rw));
-    } else {
-        compute_loc(p, lin, q.oh - rh, q.ow - rw, r, c);
-    }
-    p.loc_out[2 * n] = r;
-    p.loc_out[2 * n + 1] = c;
-    p.res_out[2 * n] = rh;
-    p.res_out[2 * n + 1] = rw;
-    if (p.user_loc) {
-        p.user_loc[2 * n] = r;
-        p.user_loc[2 * n + 1] = c;
-    }
-    if (p.user_res) {
-        p.user_res[2 * n] = rh;
-        p.user_res[2 * n + 1] = rw;
-    }
-    q.sizes[n] = (int64_t)p.fs * rh * rw;
-}
-// off[0] = 0, off[k] = sizes[0] + ... + sizes[k-1], k <= n.  One workgroup of 1024 threads (n <= 65535 per context).
-__global__ __launch_bounds__(1024) void k_scan_sizes(const int64_t *sizes, int64_t *off, int n) {
-    __shared__ int64_t part[1024];
-    const int tid = threadIdx.x, per = (n + 1023) / 1024;
-    const int lo = min(tid * per, n), hi = min(lo + per, n);
-    int64_t s = 0;
-    for (int i = lo; i < hi; ++i) s += sizes[i];
-    part[tid] = s;
-    __syncthreads();
-    for (int d = 1; d < 1024; d <<= 1) {                 // inclusive Hillis-Steele scan of the partial sums
-        const int64_t v = tid >= d ? part[tid - d] : 0;
-        __syncthreads();
-        part[tid] += v;
-        __syncthreads();
-    }
-    int64_t run = part[tid] - s;                         // exclusive prefix of this thread's chunk
-    for (int i = lo; i < hi; ++i) {
-        off[i] = run;
-        run += sizes[i];
-    }
-    if (tid == 1023) off[n] = part[1023];
-}
-
 // fov_loc / fov_res (re)initialisation for masked envs (fov_env.py:149-150,250-251)
 struct FovResetParams {
     const uint8_t *mask;

@@ -510,6 +510,8 @@ __device__ __forceinline__ float tap_dot(const LdsTab &t, int i, const float *sr
     return acc;
 }
 
+// RESIZE: compile-time out_mode == AGX_OUT_RESIZE (two instantiations: each keeps only the table families it reads in SGPRs)
+template <bool RESIZE>
 __global__ __launch_bounds__(kThreads) void k_fovea_flexible2(FlexParams g, FovParams p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int sl = blockIdx.x, n = blockIdx.y, tid = threadIdx.x;
@@ -572,7 +574,7 @@ __global__ __launch_bounds__(kThreads) void k_fovea_flexible2(FlexParams g, FovP
         }
     }
     const bool squeeze = rh > fh;                                 // rows only, fov_env.py:286
-    const bool resize = p.out_mode == AGX_OUT_RESIZE;
+    constexpr bool resize = RESIZE;
     // ---- stage the tables this window needs (L2 hits; their latency hides under the frame load)
     int toff = 0;
     LdsTab wd{}, hd{}, wb{}, hb{}, wf{}, hf{};
@@ -595,11 +597,11 @@ __global__ __launch_bounds__(kThreads) void k_fovea_flexible2(FlexParams g, FovP
     const unsigned char *win = raw + r * ow + c;
     const float kInv255 = 1.0f / 255.0f;          // resampling inputs only (<= 1 ulp from k/255); pasted pixels use lut
     const int ow4 = ow >> 2;
-    const FastDiv dv_ow4(ow4), dv_ow(ow), dv_fw(fw), dv_rw(rw);
     float4 *out4 = reinterpret_cast<float4 *>(p.obs) + ((size_t)n * p.fs + j) * (size_t)(oh * ow4);
 
     if (squeeze) {
         // P1: A[y][xf] = Wdwn(crop)      y < rh, xf < fw
+        const FastDiv dv_fw(fw);
         for (int i = tid; i < rh * fw; i += kThreads) {
             const int y = dv_fw.div(i), xf = i - y * fw;
             const int2 ln = wd.ln[xf];
@@ -617,6 +619,7 @@ __global__ __launch_bounds__(kThreads) void k_fovea_flexible2(FlexParams g, FovP
         }
         __syncthreads();
         // P3: C[yf][x] = Wbck(B)         x < rw
+        const FastDiv dv_rw(rw);
         for (int i = tid; i < fh * rw; i += kThreads) {
             const int yf = dv_rw.div(i), x = i - yf * rw;
             C[yf * ow + x] = tap_dot(wb, x, B + yf * fw, 1);
@@ -627,6 +630,7 @@ __global__ __launch_bounds__(kThreads) void k_fovea_flexible2(FlexParams g, FovP
     if (resize) {
         // E[y][xo] = Wfin(src rows): src = C (fh rows) after a squeeze, else the crop itself (rh rows)
         const int erows = squeeze ? fh : rh;
+        const FastDiv dv_ow(ow), dv_ow4(ow4);
         for (int i = tid; i < erows * ow; i += kThreads) {
             const int y = dv_ow.div(i), xo = i - y * ow;
             // the final resize is never a down-scale (r <= obs): one or two taps, unrolled with a zero second weight
@@ -685,6 +689,7 @@ __global__ __launch_bounds__(kThreads) void k_fovea_flexible2(FlexParams g, FovP
         const int64_t off = p.packed_off[n], cnt = (int64_t)rh * rw;
         if (off + (int64_t)p.fs * cnt > p.packed_cap) return;
         float *dst = p.packed + off + (int64_t)j * cnt;
+        const FastDiv dv_rw(rw);
         for (int i = tid; i < rh * rw; i += kThreads) {
             const int y = dv_rw.div(i), x = i - y * rw;
             float v;
@@ -703,6 +708,7 @@ __global__ __launch_bounds__(kThreads) void k_fovea_flexible2(FlexParams g, FovP
     // mask-out paste at (r, c) / raw crop at the origin of the obs-pitched buffer
     const int pr = (p.out_mode == AGX_OUT_MASK) ? r : 0;
     const int pc = (p.out_mode == AGX_OUT_MASK) ? c : 0;
+    const FastDiv dv_ow4(ow4);
     for (int q = tid; q < oh * ow4; q += kThreads) {
         const int row = dv_ow4.div(q), x = (q - row * ow4) * 4;
         const int y = row - pr;
