@@ -11,17 +11,22 @@ namespace agx {
 //   MODE = AGX_OUT_RESIZE: LDS s[fh][fw] -> H[fh][ow] (horizontal lerp) -> float4 rows of the
 //          84x84 output = vertical lerp of two ds_read_b128; every store is 16 B/lane, lane-linear.
 // ---------------------------------------------------------------------------------------------
+// The observation is a write-once stream of 115 MB per launch.  Rounds 1 / 2 wrote it with nontemporal stores, so that the
+// next launch (K1) does not queue behind ~115 MB of dirty L2 / Infinity-Cache lines (K1 ran ~6 us slower after plain stores).
+// Round 3 measured the cache-policy bits on this very store shape (tools/storebench.hip, 115.6 MB, same box): nt 20.1 us
+// (5.76 TB/s), plain 18.0 (6.41), sc0 18.0, **sc1 17.0 us (6.80 TB/s)**, sc1 nt 19.6.  An agent-scope (sc1) store is written
+// through the XCD's L2 towards memory at once - nothing stays dirty behind the launch either.  In the real step (same box,
+// bench.py's kernel events / us per step): K2 22.0 -> 19.9 / 52.5-53.1 -> 51.0-51.2; K3 24.5-25.0 -> 22.6-23.8 / 55.4-56.0 ->
+// 53.4-55.2; K4 24.2-25.0 -> 22.0-22.4 / 55.1-56.3 -> 53.7-53.8; K1 behind them unchanged.
+// The builtins offer no way to set sc1 on a 16-byte store, hence inline asm - which is CONVERGENT for the optimiser: a loop whose
+// trip count differs per thread cannot be unrolled around it, so the store loops run a uniform number of passes and test the
+// bound inside (unrolled, their LDS reads batch up ahead of the stores as before).  No "memory" clobber: nothing in these
+// kernels reads the observation back, and the clobber would pin every LDS read of the next pass behind the store.
 template <class T4>
 __device__ __forceinline__ void store_obs(T4 *dst, const T4 &v) {
-#ifndef AGX_K2_PLAIN_STORES
-    // write-once stream: nontemporal, so the next launch (K1) does not queue behind ~115 MB of dirty
-    // L2 / Infinity-Cache lines (measured: K1 is ~6 us faster after nontemporal obs stores)
     typedef float f4v __attribute__((ext_vector_type(4)));
     const f4v w = {v.x, v.y, v.z, v.w};
-    __builtin_nontemporal_store(w, reinterpret_cast<f4v *>(dst));
-#else
-    *dst = v;
-#endif
+    asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(dst), "v"(w));
 }
 
 // grid = (fs, N): workgroup (sl, n) owns PHYSICAL ring slot sl of env n, block = 256.
@@ -136,7 +141,9 @@ __device__ __forceinline__ void fovea_fixed_body(const G g, const FovParams &p, 
     const int ow4 = ow >> 2;
     float4 *out4 = reinterpret_cast<float4 *>(p.obs) + ((size_t)n * p.fs + j) * (size_t)(oh * ow4);
     if (MODE == AGX_OUT_MASK) {
-        for (int q = tid; q < oh * ow4; q += kThreads) {
+        for (int k_ = 0; k_ < (oh * ow4 + kThreads - 1) / kThreads; ++k_) {
+            const int q = tid + k_ * kThreads;
+            if (q >= oh * ow4) break;
             const int row = q / ow4, x = (q - row * ow4) * 4;
             float v[4] = {0.f, 0.f, 0.f, 0.f};
             if (row >= r && row < r + fh && x + 3 >= c && x < c + fw) {
@@ -172,8 +179,13 @@ __device__ __forceinline__ void fovea_fixed_body(const G g, const FovParams &p, 
     AGX_STAMP(3);
     // ---- phase D
     const float4 *H4 = reinterpret_cast<const float4 *>(H);
+    // (a uniform trip count with the bound tested inside: inline asm is convergent, and a loop whose trip count differs per
+    //  thread cannot be unrolled around it - with the compile-time geometry all 7 passes unroll and their LDS reads batch up)
+    const int nq = oh * ow4, passes = (nq + kThreads - 1) / kThreads;
 #pragma unroll 7
-    for (int q = tid; q < oh * ow4; q += kThreads) {
+    for (int k = 0; k < passes; ++k) {
+        const int q = tid + k * kThreads;
+        if (q >= nq) break;
         const int row = q / ow4, x4 = q - row * ow4;
         const Tap t = ytab_s[row];
         const float4 a = H4[t.lo * ow4 + x4];

@@ -177,7 +177,9 @@ __global__ __launch_bounds__(kThreads) void k_fovea_peripheral3(G g, Per3Params 
     const float4 *C4 = reinterpret_cast<const float4 *>(C);
     const uint32_t *raw32 = reinterpret_cast<const uint32_t *>(raw);
 #pragma unroll 7
-    for (int q = tid; q < oh * ow4; q += kThreads) {
+    for (int k_ = 0; k_ < (oh * ow4 + kThreads - 1) / kThreads; ++k_) {
+        const int q = tid + k_ * kThreads;
+        if (q >= oh * ow4) break;
         const int row = q / ow4, x4 = q - row * ow4, x = x4 * 4;
         float4 o = make_float4(0.f, 0.f, 0.f, 0.f);
         if (!t.same) {

@@ -247,7 +247,9 @@ __global__ __launch_bounds__(kThreads) void k_fovea_flexible3(G g, Flex3Params t
     float4 *out4 = reinterpret_cast<float4 *>(p.obs) + ((size_t)n * p.fs + j) * (size_t)(oh * ow4);
     if (squeeze) {
 #pragma unroll 7
-        for (int q = tid; q < oh * ow4; q += kThreads) {
+        for (int k_ = 0; k_ < (oh * ow4 + kThreads - 1) / kThreads; ++k_) {
+            const int q = tid + k_ * kThreads;
+            if (q >= oh * ow4) break;
             const int row = q / ow4, x4 = q - row * ow4;
             const int4 e = ytab_s[row];
             const float w0 = __int_as_float(e.y), w1 = __int_as_float(e.z), w2 = __int_as_float(e.w);
@@ -263,7 +265,9 @@ __global__ __launch_bounds__(kThreads) void k_fovea_flexible3(G g, Flex3Params t
         }
     } else {
 #pragma unroll 7
-        for (int q = tid; q < oh * ow4; q += kThreads) {
+        for (int k_ = 0; k_ < (oh * ow4 + kThreads - 1) / kThreads; ++k_) {
+            const int q = tid + k_ * kThreads;
+            if (q >= oh * ow4) break;
             const int row = q / ow4, x4 = q - row * ow4;
             const int4 e = ytab_s[row];
             const float w0 = __int_as_float(e.y), w1 = __int_as_float(e.z);

@@ -224,7 +224,9 @@ __global__ __launch_bounds__(kThreads) void k_fovea_flexible_raw3(G g, FlexRawPa
                 pdst[i] = unit_fast((float)win[y * wp + x]);
             }
         } else {
-            for (int q = tid; q < oh * ow4; q += kThreads) {
+            for (int k_ = 0; k_ < (oh * ow4 + kThreads - 1) / kThreads; ++k_) {
+                const int q = tid + k_ * kThreads;
+                if (q >= oh * ow4) break;
                 const int row = q / ow4, x = (q - row * ow4) * 4;
                 const int y = row - pr;
                 float v[4] = {0.f, 0.f, 0.f, 0.f};
@@ -315,7 +317,9 @@ __global__ __launch_bounds__(kThreads) void k_fovea_flexible_raw3(G g, FlexRawPa
             pdst[i] = fmaf(tp.b, E[tp.aux * ow + x], tp.a * E[tp.lo * ow + x]);
         }
     } else {
-        for (int q = tid; q < oh * ow4; q += kThreads) {
+        for (int k_ = 0; k_ < (oh * ow4 + kThreads - 1) / kThreads; ++k_) {
+            const int q = tid + k_ * kThreads;
+            if (q >= oh * ow4) break;
             const int row = q / ow4, x = (q - row * ow4) * 4;
             const int y = row - pr;
             float v[4] = {0.f, 0.f, 0.f, 0.f};
