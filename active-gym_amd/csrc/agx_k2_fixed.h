@@ -18,15 +18,25 @@ namespace agx {
 // through the XCD's L2 towards memory at once - nothing stays dirty behind the launch either.  In the real step (same box,
 // bench.py's kernel events / us per step): K2 22.0 -> 19.9 / 52.5-53.1 -> 51.0-51.2; K3 24.5-25.0 -> 22.6-23.8 / 55.4-56.0 ->
 // 53.4-55.2; K4 24.2-25.0 -> 22.0-22.4 / 55.1-56.3 -> 53.7-53.8; K1 behind them unchanged.
-// The builtins offer no way to set sc1 on a 16-byte store, hence inline asm - which is CONVERGENT for the optimiser: a loop whose
-// trip count differs per thread cannot be unrolled around it, so the store loops run a uniform number of passes and test the
-// bound inside (unrolled, their LDS reads batch up ahead of the stores as before).  No "memory" clobber: nothing in these
-// kernels reads the observation back, and the clobber would pin every LDS read of the next pass behind the store.
-template <class T4>
-__device__ __forceinline__ void store_obs(T4 *dst, const T4 &v) {
-    typedef float f4v __attribute__((ext_vector_type(4)));
-    const f4v w = {v.x, v.y, v.z, v.w};
-    asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(dst), "v"(w));
+// A raw buffer store carries the bit (aux 16 = sc1 on gfx940+) and stays an ordinary store for the compiler (an inline-asm store
+// does not: the hazard recogniser cannot see that its four data VGPRs must not be overwritten by the very next VALU
+// instruction, and the first sc1 build produced a few hundred wrong observation values per launch that way).  One buffer
+// resource per workgroup = its output frame: the pointer is wave-uniform by construction, out-of-range offsets are dropped.
+struct ObsOut {
+    __amdgpu_buffer_rsrc_t rs;
+};
+__device__ __forceinline__ ObsOut obs_out(float4 *frame, int n_float4) {
+    const uintptr_t a = reinterpret_cast<uintptr_t>(frame);
+    const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)a), hi = __builtin_amdgcn_readfirstlane((uint32_t)(a >> 32));
+    void *p = reinterpret_cast<void *>(((uintptr_t)hi << 32) | lo);
+    ObsOut o;
+    o.rs = __builtin_amdgcn_make_buffer_rsrc(p, 0, n_float4 * 16, 0x00027000);
+    return o;
+}
+__device__ __forceinline__ void store_obs(const ObsOut &o, int q, const float4 &v) {
+    typedef uint32_t u4v __attribute__((ext_vector_type(4)));
+    const u4v w = {__float_as_uint(v.x), __float_as_uint(v.y), __float_as_uint(v.z), __float_as_uint(v.w)};
+    __builtin_amdgcn_raw_buffer_store_b128(w, o.rs, q * 16, 0, 16 /* sc1 */);
 }
 
 // grid = (fs, N): workgroup (sl, n) owns PHYSICAL ring slot sl of env n, block = 256.
@@ -140,6 +150,7 @@ __device__ __forceinline__ void fovea_fixed_body(const G g, const FovParams &p, 
     }
     const int ow4 = ow >> 2;
     float4 *out4 = reinterpret_cast<float4 *>(p.obs) + ((size_t)n * p.fs + j) * (size_t)(oh * ow4);
+    const ObsOut oout = obs_out(out4, oh * ow4);
     if (MODE == AGX_OUT_MASK) {
         for (int k_ = 0; k_ < (oh * ow4 + kThreads - 1) / kThreads; ++k_) {
             const int q = tid + k_ * kThreads;
@@ -152,7 +163,7 @@ __device__ __forceinline__ void fovea_fixed_body(const G g, const FovParams &p, 
                 for (int k = 0; k < 4; ++k)
                     if (x + k >= c && x + k < c + fw) v[k] = unit_fast((float)((w >> (8 * k)) & 0xFF));
             }
-            store_obs(&out4[q], make_float4(v[0], v[1], v[2], v[3]));
+            store_obs(oout, q, make_float4(v[0], v[1], v[2], v[3]));
         }
         return;
     }
@@ -197,7 +208,7 @@ __device__ __forceinline__ void fovea_fixed_body(const G g, const FovParams &p, 
         o.y = fmaf(t.b, b.y, t.a * a.y);
         o.z = fmaf(t.b, b.z, t.a * a.z);
         o.w = fmaf(t.b, b.w, t.a * a.w);
-        store_obs(&out4[q], o);
+        store_obs(oout, q, o);
     }
     AGX_STAMP(4);
 }

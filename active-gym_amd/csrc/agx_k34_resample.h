@@ -341,6 +341,7 @@ __global__ __launch_bounds__(kThreads) void k_fovea_peripheral2(PerParams g, Fov
     const int ow4 = ow >> 2;
     const FastDiv dv_ow4(ow4), dv_pw(pw), dv_ow(ow);
     float4 *out4 = reinterpret_cast<float4 *>(p.obs) + ((size_t)n * p.fs + j) * (size_t)(oh * ow4);
+    const ObsOut oout = obs_out(out4, oh * ow4);
     if (!g.same) {
         // pass 0: A[y][xp] = sum_k (w0[xp][k] / 255) * raw[y][lo + k]
         // The pass-0 weights carry the 1/255 (host side), so bytes convert with v_cvt_f32_ubyteN and no
@@ -458,7 +459,7 @@ __global__ __launch_bounds__(kThreads) void k_fovea_peripheral2(PerParams g, Fov
             if (g.same || (x + 2 >= c && x + 2 < c + fw)) o.z = lut[(wv >> 16) & 0xFF];
             if (g.same || (x + 3 >= c && x + 3 < c + fw)) o.w = lut[wv >> 24];
         }
-        store_obs(&out4[q], o);
+        store_obs(oout, q, o);
     }
 }
 
@@ -598,6 +599,7 @@ __global__ __launch_bounds__(kThreads) void k_fovea_flexible2(FlexParams g, FovP
     const float kInv255 = 1.0f / 255.0f;          // resampling inputs only (<= 1 ulp from k/255); pasted pixels use lut
     const int ow4 = ow >> 2;
     float4 *out4 = reinterpret_cast<float4 *>(p.obs) + ((size_t)n * p.fs + j) * (size_t)(oh * ow4);
+    const ObsOut oout = obs_out(out4, oh * ow4);
 
     if (squeeze) {
         // P1: A[y][xf] = Wdwn(crop)      y < rh, xf < fw
@@ -681,7 +683,7 @@ __global__ __launch_bounds__(kThreads) void k_fovea_flexible2(FlexParams g, FovP
                     o.w = fmaf(fa[a], v.w, o.w);
                 }
             }
-            store_obs(&out4[q], o);
+            store_obs(oout, q, o);
         }
         return;
     }
@@ -734,7 +736,7 @@ __global__ __launch_bounds__(kThreads) void k_fovea_flexible2(FlexParams g, FovP
                 }
             }
         }
-        store_obs(&out4[q], make_float4(v[0], v[1], v[2], v[3]));
+        store_obs(oout, q, make_float4(v[0], v[1], v[2], v[3]));
     }
 }
 

@@ -118,6 +118,7 @@ __global__ __launch_bounds__(kThreads) void k_fovea_peripheral3(G g, Per3Params 
 
     const int ow4 = ow >> 2;
     float4 *out4 = reinterpret_cast<float4 *>(p.obs) + ((size_t)n * p.fs + j) * (size_t)(oh * ow4);
+    const ObsOut oout = obs_out(out4, oh * ow4);
     if (!t.same) {
         // ---- pass 0: A[y][xp] = sum_k (w0[xp][k] / 255) * raw[y][lo + k]; bytes through aligned dwords + alignbyte
         if (y00 < per0) {
@@ -201,7 +202,7 @@ __global__ __launch_bounds__(kThreads) void k_fovea_peripheral3(G g, Per3Params 
             if (t.same || d0 + 2 < (unsigned)fw) o.z = unit_fast((float)((wv >> 16) & 0xFF));
             if (t.same || d0 + 3 < (unsigned)fw) o.w = unit_fast((float)(wv >> 24));
         }
-        store_obs(&out4[q], o);
+        store_obs(oout, q, o);
     }
 }
 

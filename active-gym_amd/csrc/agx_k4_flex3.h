@@ -245,6 +245,7 @@ __global__ __launch_bounds__(kThreads) void k_fovea_flexible3(G g, Flex3Params t
     const int ow4 = ow >> 2;
     const float4 *E4 = reinterpret_cast<const float4 *>(E);
     float4 *out4 = reinterpret_cast<float4 *>(p.obs) + ((size_t)n * p.fs + j) * (size_t)(oh * ow4);
+    const ObsOut oout = obs_out(out4, oh * ow4);
     if (squeeze) {
 #pragma unroll 7
         for (int k_ = 0; k_ < (oh * ow4 + kThreads - 1) / kThreads; ++k_) {
@@ -261,7 +262,7 @@ __global__ __launch_bounds__(kThreads) void k_fovea_flexible3(G g, Flex3Params t
             o.y = fmaf(w2, d.y, fmaf(w1, b.y, w0 * a.y));
             o.z = fmaf(w2, d.z, fmaf(w1, b.z, w0 * a.z));
             o.w = fmaf(w2, d.w, fmaf(w1, b.w, w0 * a.w));
-            store_obs(&out4[q], o);
+            store_obs(oout, q, o);
         }
     } else {
 #pragma unroll 7
@@ -278,7 +279,7 @@ __global__ __launch_bounds__(kThreads) void k_fovea_flexible3(G g, Flex3Params t
             o.y = fmaf(w1, b.y, w0 * a.y);
             o.z = fmaf(w1, b.z, w0 * a.z);
             o.w = fmaf(w1, b.w, w0 * a.w);
-            store_obs(&out4[q], o);
+            store_obs(oout, q, o);
         }
     }
 }

@@ -189,6 +189,7 @@ __global__ __launch_bounds__(kThreads) void k_fovea_flexible_raw3(G g, FlexRawPa
     const int ow4 = ow >> 2;
     float *pdst = PACKED ? p.packed + poff + (int64_t)j * cnt : nullptr;
     float4 *out4 = PACKED ? nullptr : reinterpret_cast<float4 *>(p.obs) + ((size_t)n * p.fs + j) * (size_t)(oh * ow4);
+    const ObsOut oout = obs_out(out4, oh * ow4);
     const int pr = OUT == AGX_OUT_MASK ? r : 0, pc = OUT == AGX_OUT_MASK ? c : 0;   // where the crop lands in a full frame
     const FastDiv dv_rw(rw);
 
@@ -237,7 +238,7 @@ __global__ __launch_bounds__(kThreads) void k_fovea_flexible_raw3(G g, FlexRawPa
                         if (xx >= 0 && xx < rw) v[k] = unit_fast((float)win[y * wp + xx]);
                     }
                 }
-                store_obs(&out4[q], make_float4(v[0], v[1], v[2], v[3]));
+                store_obs(oout, q, make_float4(v[0], v[1], v[2], v[3]));
             }
         }
         return;
@@ -331,7 +332,7 @@ __global__ __launch_bounds__(kThreads) void k_fovea_flexible_raw3(G g, FlexRawPa
                     if (xx >= 0 && xx < rw) v[k] = fmaf(tp.b, E[tp.aux * ow + xx], tp.a * E[tp.lo * ow + xx]);
                 }
             }
-            store_obs(&out4[q], make_float4(v[0], v[1], v[2], v[3]));
+            store_obs(oout, q, make_float4(v[0], v[1], v[2], v[3]));
         }
     }
 }

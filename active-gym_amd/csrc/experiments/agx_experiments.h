@@ -623,6 +623,7 @@ __global__ __launch_bounds__(kThreads) void k_fovea_fixed2(G g, FovParams p) {
         int j = sl0 + half - head;
         if (j < 0) j += p.fs;
         float4 *out4 = reinterpret_cast<float4 *>(p.obs) + ((size_t)n * p.fs + j) * (size_t)(oh * ow4);
+        const ObsOut oout = obs_out(out4, oh * ow4);
 #pragma unroll 7
         for (int q = tid; q < oh * ow4; q += kThreads) {
             const int row = q / ow4, x4 = q - row * ow4;
@@ -634,7 +635,7 @@ __global__ __launch_bounds__(kThreads) void k_fovea_fixed2(G g, FovParams p) {
             o.y = fmaf(t.b, b.y, t.a * a.y);
             o.z = fmaf(t.b, b.z, t.a * a.z);
             o.w = fmaf(t.b, b.w, t.a * a.w);
-            store_obs(&out4[q], o);
+            store_obs(oout, q, o);
         }
     }
 }
