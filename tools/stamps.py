@@ -46,3 +46,16 @@ print("mean resident waves per CU over time (us : waves):")
 print("  " + "  ".join(f"{t:.0f}:{o:.0f}" for t, o in zip(ts[::3], occ.mean(0)[::3])))
 last_start = np.array([((rt0[cuid == c] - t0) / 100.0).max() for c in ids])
 print("last wave start per CU: mean %.1f us  max %.1f us ; kernel span %.1f" % (last_start.mean(), last_start.max(), span))
+# turnaround of a wave slot: from the last stamp of one wave to the first stamp of the next wave in the same (CU, SIMD, slot).
+# That interval holds the end of the old wave (its last store, s_endpgm), the dispatcher's hand-over - a workgroup is admitted
+# when all of its waves' slots and its LDS are free - and the new wave's start (SGPR / VGPR init, kernel-argument s_loads).
+simd = (hw >> 4) & 3; wslot = hw & 0xF
+slot = cuid * 64 + simd * 16 + wslot
+order = np.lexsort((rt0, slot))
+so, a, b = slot[order], rt0[order], rt1[order]
+same = so[1:] == so[:-1]
+gaps = ((a[1:] - b[:-1]) / 100.0)[same]
+print("wave-slot turnaround (end stamp -> next wave's first stamp, same CU / SIMD / slot): mean %.2f us  p50 %.2f  p90 %.2f  (n = %d); "
+      "distinct slots used %d (%.1f per CU)" % (gaps.mean(), np.median(gaps), np.percentile(gaps, 90), len(gaps), len(np.unique(slot)), len(np.unique(slot)) / len(ids)))
+busy = (b - a).sum() / 100.0
+print("slot time inside the stamps: %.0f wave-us = %.1f %% of (distinct slots x kernel span)" % (busy, 100.0 * busy / (len(np.unique(slot)) * span)))
