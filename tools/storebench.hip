@@ -24,6 +24,17 @@ __global__ __launch_bounds__(256) void k_frame(f4 *out, float v) {
     const size_t base = ((size_t)blockIdx.y * 4 + blockIdx.x) * 1764;
     for (int q = threadIdx.x; q < 1764; q += 256) st16<POL>(&out[base + q], f4{v, v + q, v, v});
 }
+// (A') the same with pseudo-random k/255 values (the real observations; (A)'s are three constants and one ramp per float4)
+template <int POL>
+__global__ __launch_bounds__(256) void k_frame_rand(f4 *out, unsigned seed) {
+    const size_t base = ((size_t)blockIdx.y * 4 + blockIdx.x) * 1764;
+    for (int q = threadIdx.x; q < 1764; q += 256) {
+        unsigned x = ((unsigned)(base + q) * 2654435761u) ^ seed;
+        x ^= x >> 16; x *= 0x7feb352du; x ^= x >> 15;
+        const float k = 1.0f / 255.0f;
+        st16<POL>(&out[base + q], f4{(float)(x & 255u) * k, (float)((x >> 8) & 255u) * k, (float)((x >> 16) & 255u) * k, (float)(x >> 24) * k});
+    }
+}
 // (B) the same bytes, each LANE writing 64 contiguous bytes per pass (4 float4): a wave covers 4 KB per pass
 template <int POL>
 __global__ __launch_bounds__(256) void k_lane64(f4 *out, float v, size_t n4) {
@@ -64,6 +75,11 @@ int main() {
 #define RUNA(P) { float us = timeit([&](int r) { hipLaunchKernelGGL(k_frame<P>, dim3(4, N), dim3(256), 0, 0, ob, (float)r); }, R); \
                   printf("A frame/WG, 16 B lanes, %-11s %7.2f us -> %.2f TB/s\n", pol[P], us, bytes / us / 1e6); }
     RUNA(0) RUNA(1) RUNA(2) RUNA(3) RUNA(4) RUNA(5) RUNA(6)
+#define RUNAR(P) { float us = timeit([&](int r) { hipLaunchKernelGGL(k_frame_rand<P>, dim3(4, N), dim3(256), 0, 0, ob, (unsigned)(r * 7919 + 1)); }, R); \
+                  printf("A' frame/WG, random k/255, %-11s %7.2f us -> %.2f TB/s\n", pol[P], us, bytes / us / 1e6); }
+    RUNAR(0) RUNAR(1) RUNAR(2) RUNAR(0) RUNAR(2)
+    { float us = timeit([&](int r) { hipLaunchKernelGGL(k_frame<2>, dim3(4, N), dim3(256), 0, 0, ob, 0.0f); }, R);
+      printf("A  frame/WG, sc1, f4{0, q, 0, 0}          %7.2f us -> %.2f TB/s\n", us, bytes / us / 1e6); }
 #define RUNB(P, G) { float us = timeit([&](int r) { hipLaunchKernelGGL(k_lane64<P>, dim3(G), dim3(256), 0, 0, ob, (float)r, n4); }, R); \
                   printf("B 64 B per lane, %5d WGs, %-11s %7.2f us -> %.2f TB/s\n", G, pol[P], us, bytes / us / 1e6); }
     RUNB(1, 2048) RUNB(1, 4096) RUNB(1, 7056) RUNB(0, 4096)
