@@ -48,7 +48,15 @@ __global__ __launch_bounds__(kThreads) void k_full(StackParams p) {
     o.y = unit((v >> 8) & 0xFF);
     o.z = unit((v >> 16) & 0xFF);
     o.w = unit(v >> 24);
-    reinterpret_cast<float4 *>(p.out_f32)[((size_t)n * p.fs + j) * p.words + i] = o;
+    // write-once observation stream: written through (sc1) like the fovea kernels' (store_obs, agx_k2_fixed.h); the frame of
+    // (n, j) is the buffer - wave-uniform by construction
+    const uintptr_t a = reinterpret_cast<uintptr_t>(reinterpret_cast<float4 *>(p.out_f32) + ((size_t)n * p.fs + j) * p.words);
+    const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)a), hi = __builtin_amdgcn_readfirstlane((uint32_t)(a >> 32));
+    const __amdgpu_buffer_rsrc_t rs =
+        __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<void *>(((uintptr_t)hi << 32) | lo), 0, p.words * 16, 0x00027000);
+    typedef uint32_t u4v __attribute__((ext_vector_type(4)));
+    const u4v w = {__float_as_uint(o.x), __float_as_uint(o.y), __float_as_uint(o.z), __float_as_uint(o.w)};
+    __builtin_amdgcn_raw_buffer_store_b128(w, rs, i * 16, 0, 16 /* sc1 */);
 }
 
 }  // namespace agx

@@ -130,6 +130,7 @@ __global__ __launch_bounds__(kThreads) void k_fovea_generic(GeomR g, FovParams p
     const int ow4 = ow >> 2;
     const FastDiv dv_ow4(ow4);
     float4 *out4 = reinterpret_cast<float4 *>(p.obs) + ((size_t)n * p.fs + j) * (size_t)(oh * ow4);
+    const ObsOut oout = obs_out(out4, oh * ow4);
 
     if (KIND == AGX_KIND_PERIPHERAL) {
         // S = full frame; periphery = expand(squeeze(S)); fovea pasted at full resolution
@@ -172,7 +173,7 @@ __global__ __launch_bounds__(kThreads) void k_fovea_generic(GeomR g, FovParams p
                 else
                     v[k] = apply_tap(d, t, C + xx, ow);
             }
-            out4[q] = make_float4(v[0], v[1], v[2], v[3]);
+            store_obs(oout, q, make_float4(v[0], v[1], v[2], v[3]));
         }
         return;
     }
@@ -219,8 +220,8 @@ __global__ __launch_bounds__(kThreads) void k_fovea_generic(GeomR g, FovParams p
             const Tap t = tab[row];
             const float4 a = H4[t.lo * ow4 + x4];
             const float4 b = H4[t.aux * ow4 + x4];
-            out4[q] = make_float4(t.a * a.x + t.b * b.x, t.a * a.y + t.b * b.y,
-                                  t.a * a.z + t.b * b.z, t.a * a.w + t.b * b.w);
+            store_obs(oout, q, make_float4(t.a * a.x + t.b * b.x, t.a * a.y + t.b * b.y,
+                                           t.a * a.z + t.b * b.z, t.a * a.w + t.b * b.w));
         }
         return;
     }
@@ -245,7 +246,7 @@ __global__ __launch_bounds__(kThreads) void k_fovea_generic(GeomR g, FovParams p
                 if (xx >= 0 && xx < rw) v[k] = cur[y * rw + xx];
             }
         }
-        out4[q] = make_float4(v[0], v[1], v[2], v[3]);
+        store_obs(oout, q, make_float4(v[0], v[1], v[2], v[3]));
     }
 }
 

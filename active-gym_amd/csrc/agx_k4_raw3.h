@@ -26,6 +26,23 @@
 namespace agx {
 
 constexpr int kRawPacked = 100;
+
+// one float of a packed crop, written through like the observations (store_obs, agx_k2_fixed.h): the crop [rh][rw] of one stacked
+// frame is the buffer (4-byte aligned only - packed offsets are arbitrary - hence dword stores)
+struct PackedOut {
+    __amdgpu_buffer_rsrc_t rs;
+};
+__device__ __forceinline__ PackedOut packed_out(float *crop, int n_floats) {
+    const uintptr_t a = reinterpret_cast<uintptr_t>(crop);
+    const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)a), hi = __builtin_amdgcn_readfirstlane((uint32_t)(a >> 32));
+    void *q = reinterpret_cast<void *>(((uintptr_t)hi << 32) | lo);
+    PackedOut o;
+    o.rs = __builtin_amdgcn_make_buffer_rsrc(q, 0, crop ? n_floats * 4 : 0, 0x00027000);
+    return o;
+}
+__device__ __forceinline__ void store_packed(const PackedOut &o, int i, float v) {
+    __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), o.rs, i * 4, 0, 16 /* sc1 */);
+}
 constexpr int kScanEnvsPerBlock = kThreads;      // one env per thread of a 256-thread scan workgroup
 
 struct FlexRawParams {
@@ -188,6 +205,8 @@ __global__ __launch_bounds__(kThreads) void k_fovea_flexible_raw3(G g, FlexRawPa
     const uint8_t *frame = p.ring + ((size_t)n * p.fs + sl) * (size_t)fbytes;
     const int ow4 = ow >> 2;
     float *pdst = PACKED ? p.packed + poff + (int64_t)j * cnt : nullptr;
+    // packed crops are a write-once stream like the observations: written through (sc1), one buffer resource per crop
+    const PackedOut pout = packed_out(pdst, cnt);
     float4 *out4 = PACKED ? nullptr : reinterpret_cast<float4 *>(p.obs) + ((size_t)n * p.fs + j) * (size_t)(oh * ow4);
     const ObsOut oout = obs_out(out4, oh * ow4);
     const int pr = OUT == AGX_OUT_MASK ? r : 0, pc = OUT == AGX_OUT_MASK ? c : 0;   // where the crop lands in a full frame
@@ -222,7 +241,7 @@ __global__ __launch_bounds__(kThreads) void k_fovea_flexible_raw3(G g, FlexRawPa
         if (PACKED) {
             for (int i = tid; i < cnt; i += kThreads) {
                 const int y = dv_rw.div(i), x = i - y * rw;
-                pdst[i] = unit_fast((float)win[y * wp + x]);
+                store_packed(pout, i, unit_fast((float)win[y * wp + x]));
             }
         } else {
             for (int k_ = 0; k_ < (oh * ow4 + kThreads - 1) / kThreads; ++k_) {
@@ -315,7 +334,7 @@ __global__ __launch_bounds__(kThreads) void k_fovea_flexible_raw3(G g, FlexRawPa
         for (int i = tid; i < cnt; i += kThreads) {
             const int y = dv_rw.div(i), x = i - y * rw;
             const Tap tp = ytab_s[y];
-            pdst[i] = fmaf(tp.b, E[tp.aux * ow + x], tp.a * E[tp.lo * ow + x]);
+            store_packed(pout, i, fmaf(tp.b, E[tp.aux * ow + x], tp.a * E[tp.lo * ow + x]));
         }
     } else {
         for (int k_ = 0; k_ < (oh * ow4 + kThreads - 1) / kThreads; ++k_) {

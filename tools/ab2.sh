@@ -1,7 +1,7 @@
 #!/bin/bash
 # usage: tools/ab2.sh name... ; bench.py (300 steps, kernel events) with active-gym_amd/lib/libagx_<name>.so, default library first and last
 set -u
-B="python3 bench.py --steps 300 --warmup 20 --no-cpu-baseline --no-e2e"
+B="python3 bench.py --steps 300 --warmup 20 --no-cpu-baseline --no-e2e ${BENCH_ARGS:-}"
 sum() { python3 -c "
 import json,sys
 d=json.loads(open(sys.argv[1]).read().strip().split('\n')[-1])
