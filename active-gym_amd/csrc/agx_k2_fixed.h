@@ -39,6 +39,22 @@ __device__ __forceinline__ void store_obs(const ObsOut &o, int q, const float4 &
     __builtin_amdgcn_raw_buffer_store_b128(w, o.rs, q * 16, 0, 16 /* sc1 */);
 }
 
+// one float of a raw crop (fixed: [fh][fw]; flexible, packed: [rh][rw] at an arbitrary 4-byte aligned offset - hence dword stores),
+// written through like the full-size observations: the crop of one stacked frame is the buffer
+struct PackedOut {
+    __amdgpu_buffer_rsrc_t rs;
+};
+__device__ __forceinline__ PackedOut packed_out(float *crop, int n_floats) {
+    const uintptr_t a = reinterpret_cast<uintptr_t>(crop);
+    const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)a), hi = __builtin_amdgcn_readfirstlane((uint32_t)(a >> 32));
+    void *q = reinterpret_cast<void *>(((uintptr_t)hi << 32) | lo);
+    PackedOut o;
+    o.rs = __builtin_amdgcn_make_buffer_rsrc(q, 0, crop ? n_floats * 4 : 0, 0x00027000);
+    return o;
+}
+__device__ __forceinline__ void store_packed(const PackedOut &o, int i, float v) {
+    __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), o.rs, i * 4, 0, 16 /* sc1 */);
+}
 // grid = (fs, N): workgroup (sl, n) owns PHYSICAL ring slot sl of env n, block = 256.
 // Prologue: the small state loads (action, fov_loc, head) and this thread's taps go out first; the scalar chain action ->
 // rint(clip(..)) -> (r, c) runs as soon as the state has arrived and moves to SGPRs; then ONLY the window of the slot is
@@ -46,7 +62,7 @@ __device__ __forceinline__ void store_obs(const ObsOut &o, int q, const float4 &
 // rounded quotient).
 //   RESIZE: H[fh][ow] = horizontal lerp of the window rows (thread = fixed column x, rows y = yb+3k),
 //           then each output float4 is the vertical lerp of two ds_read_b128; stores are 16 B per
-//           lane, lane-linear, 1 KiB per wave at 1-KiB steps, nontemporal.
+//           lane, lane-linear, 1 KiB per wave at 1-KiB steps, written through (sc1, store_obs above).
 // (ablation of the previous serial version at N=1024: loc chain 5.8 us, loc-dependent window load
 //  6.3 us, H pass with a tap load per iteration 7.3 us, row-tap loads 2.1 us of a 32.7 us launch.)
 // COHERENT: the frame is read with agent-scope loads (global_load_dword sc1: served by L2, never by this CU's L1) - for a
@@ -141,10 +157,10 @@ __device__ __forceinline__ void fovea_fixed_body(const G g, const FovParams &p, 
     const int xcol = tid % ow, yb = tid / ow;                         // phase-C column / first row
     const unsigned char *win = raw + c;                               // window origin inside the LDS image (row r of the frame = row 0)
     if (MODE == AGX_OUT_RAW) {
-        float *out = p.obs + ((size_t)n * p.fs + j) * (size_t)(fh * fw);
+        const PackedOut cout = packed_out(p.obs + ((size_t)n * p.fs + j) * (size_t)(fh * fw), fh * fw);
         for (int i = tid; i < fh * fw; i += kThreads) {
             const int y = i / fw, x = i - y * fw;
-            out[i] = unit_fast((float)win[y * wp + x]);
+            store_packed(cout, i, unit_fast((float)win[y * wp + x]));
         }
         return;
     }

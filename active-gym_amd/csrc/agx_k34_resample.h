@@ -256,7 +256,7 @@ __global__ __launch_bounds__(kThreads) void k_fovea_generic(GeomR g, FovParams p
 // The four separable passes use tap tables built on the HOST at agx_create (ATen's arithmetic in
 // double, weights normalised, narrowed to f32): per output index {lo, n} and n weights.
 //   raw u8 frame --W squeeze--> A[oh][pw] --H squeeze--> B[ph][pw] --W expand--> C[ph][ow]
-//   --H expand, fused with the full-resolution fovea paste and the nontemporal store.
+//   --H expand, fused with the full-resolution fovea paste and the written-through (sc1) store.
 // u8 -> f32 through the 256-entry LDS table.  ~20 KB LDS for 84/20 (C aliases A): 8 workgroups per CU
 // (the generic kernel it replaces needed 43 KB and built its taps in f64 on the device).
 // ---------------------------------------------------------------------------------------------

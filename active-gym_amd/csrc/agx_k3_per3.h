@@ -174,7 +174,7 @@ __global__ __launch_bounds__(kThreads) void k_fovea_peripheral3(G g, Per3Params 
         }
         __syncthreads();
     }
-    // ---- pass 3: H expand, the fovea pasted at full resolution, 16-B nontemporal stores
+    // ---- pass 3: H expand, the fovea pasted at full resolution, 16-B written-through (sc1) stores
     const float4 *C4 = reinterpret_cast<const float4 *>(C);
     const uint32_t *raw32 = reinterpret_cast<const uint32_t *>(raw);
 #pragma unroll 7

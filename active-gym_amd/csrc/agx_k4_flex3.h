@@ -16,7 +16,7 @@
 // every loop has a scalar trip count and every thread a fixed role per pass:
 //   Hdwn : thread = (output row yf = tid / 8, column phase tid % 8), its row's taps in registers
 //   W    : thread = output column tid % ow (its taps in registers), rows tid / ow + k * (256 / ow)
-//   final: thread = float4 q = tid + 256 k of the frame, row taps from a small LDS table; 16-B nontemporal stores
+//   final: thread = float4 q = tid + 256 k of the frame, row taps from a small LDS table; 16-B written-through (sc1) stores
 // The tables a thread needs and the window's rows of the slot are requested as soon as the env's state has arrived.
 // LDS: R0 = raw frame (+ slack rows read with zero weights) aliased by E on the squeeze path | R1 = D, or E on the
 // plain path | row taps: 21.5 KB for 84x84 / 30x30 -> 7 workgroups per CU.

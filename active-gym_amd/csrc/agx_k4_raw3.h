@@ -27,22 +27,6 @@ namespace agx {
 
 constexpr int kRawPacked = 100;
 
-// one float of a packed crop, written through like the observations (store_obs, agx_k2_fixed.h): the crop [rh][rw] of one stacked
-// frame is the buffer (4-byte aligned only - packed offsets are arbitrary - hence dword stores)
-struct PackedOut {
-    __amdgpu_buffer_rsrc_t rs;
-};
-__device__ __forceinline__ PackedOut packed_out(float *crop, int n_floats) {
-    const uintptr_t a = reinterpret_cast<uintptr_t>(crop);
-    const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)a), hi = __builtin_amdgcn_readfirstlane((uint32_t)(a >> 32));
-    void *q = reinterpret_cast<void *>(((uintptr_t)hi << 32) | lo);
-    PackedOut o;
-    o.rs = __builtin_amdgcn_make_buffer_rsrc(q, 0, crop ? n_floats * 4 : 0, 0x00027000);
-    return o;
-}
-__device__ __forceinline__ void store_packed(const PackedOut &o, int i, float v) {
-    __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), o.rs, i * 4, 0, 16 /* sc1 */);
-}
 constexpr int kScanEnvsPerBlock = kThreads;      // one env per thread of a 256-thread scan workgroup
 
 struct FlexRawParams {
