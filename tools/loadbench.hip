@@ -33,6 +33,19 @@ __global__ __launch_bounds__(256) void k_x3(const uint8_t *frames, uint32_t *out
     if (acc == 0x12345678u) out[0] = acc;
 }
 
+// launch-rate probes: kernels that do (almost) nothing, in K1's grid and in coarser / finer ones
+__global__ void k_empty(uint32_t *out) { if (threadIdx.x == 1023 && blockIdx.x == 0x7fffffff) out[0] = 1; }
+template <int VG>      // the same with VG live VGPRs per thread (register file pressure changes how many waves a SIMD admits)
+__global__ void k_empty_regs(uint32_t *out, const uint32_t *in) {
+    uint32_t v[VG];
+#pragma unroll
+    for (int i = 0; i < VG; ++i) v[i] = in[(threadIdx.x + i * 7) & 1023];
+    uint32_t a = 0;
+#pragma unroll
+    for (int i = 0; i < VG; ++i) a ^= v[i];
+    if (a == 0x12345678u) out[0] = a;
+}
+
 // pseudo-random bytes (the bench's screens are random; hipMemset leaves a constant pattern)
 __global__ void k_fill(uint32_t *p, size_t n, uint32_t seed) {
     for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
@@ -66,6 +79,19 @@ int main(int argc, char **argv) {
         for (int r = 0; r < R; ++r) hipLaunchKernelGGL(k_x3<AUX>, dim3(7, N), dim3(256), lds, 0, bufs[r % POOL], out); \
         hipEventRecord(e1); hipEventSynchronize(e1); float ms; hipEventElapsedTime(&ms, e0, e1); \
         printf("K1 load shape, %-12s %7.2f us -> %.2f TB/s (algorithmic 165.2 MB)\n", NAME, ms / R * 1e3, alg / (ms / R * 1e-3) / 1e12); }
+#define RUNE(GX, GY, BT, LDS, NAME) { for (int r = 0; r < 5; ++r) hipLaunchKernelGGL(k_empty, dim3(GX, GY), dim3(BT), LDS, 0, out); \
+        hipDeviceSynchronize(); hipEventRecord(e0); \
+        for (int r = 0; r < R; ++r) hipLaunchKernelGGL(k_empty, dim3(GX, GY), dim3(BT), LDS, 0, out); \
+        hipEventRecord(e1); hipEventSynchronize(e1); float ms; hipEventElapsedTime(&ms, e0, e1); \
+        printf("empty kernel, %-44s %7.2f us per launch -> %.0f workgroups / us\n", NAME, ms / R * 1e3, (double)(GX) * (GY) / (ms / R * 1e3)); }
+    RUNE(7, 1024, 256, 0, "grid (7, 1024) x 256, no LDS")
+    RUNE(7, 1024, 256, 16128, "grid (7, 1024) x 256, 16 KB LDS")
+    RUNE(7, 512, 512, 32256, "grid (7, 512) x 512, 32 KB LDS")
+    RUNE(7, 256, 1024, 64512, "grid (7, 256) x 1024, 63 KB LDS")
+    RUNE(7, 2048, 128, 8064, "grid (7, 2048) x 128, 8 KB LDS")
+    RUNE(4, 1024, 256, 13600, "grid (4, 1024) x 256, 13 KB LDS (K2)")
+    RUNE(1, 1024, 256, 16128, "grid (1, 1024) x 256, 16 KB LDS")
+    RUNE(1, 256, 256, 16128, "grid (1, 256) x 256, 16 KB LDS")
     RUN(0, "plain") RUN(2, "nt") RUN(16, "sc1") RUN(17, "sc0 sc1") RUN(18, "sc1 nt") RUN(19, "sc0 sc1 nt") RUN(1, "sc0") RUN(3, "sc0 nt")
     RUN(0, "plain") RUN(2, "nt")
     return 0;
