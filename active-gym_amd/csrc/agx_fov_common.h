@@ -87,6 +87,66 @@ __device__ __forceinline__ LocIn load_loc_inputs(const FovParams &p, int n) {
     in.w[3] = wide ? a1.y : 0u;
     return in;
 }
+// The same inputs + the ring head through the SCALAR cache (the env index is workgroup-uniform): four s_loads, one wait.  A
+// scalar round trip is shorter than a vector one, and this hop sits in front of every workgroup's window fetch (K2: removing it
+// altogether was worth 1.9 us of 20.5, profiles/r03_k2_ablation.txt).  `head` may be null (returns 0).
+__device__ __forceinline__ LocIn load_loc_inputs_scalar(const FovParams &p, int n, const int32_t *head_ptr, int &head) {
+    const bool wide = p.action_dt == AGX_DT_F64 || p.action_dt == AGX_DT_I64;
+    const int32_t *loc = p.loc_in + 2 * n;
+    const char *base = p.action ? static_cast<const char *>(p.action) + (size_t)n * (wide ? 16 : 8)
+                                : reinterpret_cast<const char *>(loc);
+    const char *base1 = base + ((wide && p.action) ? 8 : 0);
+    const int32_t *hp = head_ptr ? head_ptr + n : loc;
+    int2 rc;
+    uint2 a0, a1;
+    int32_t h;
+    asm volatile("s_load_dwordx2 %0, %4, 0x0\n\ts_load_dwordx2 %1, %5, 0x0\n\ts_load_dwordx2 %2, %6, 0x0\n\ts_load_dword %3, %7, 0x0\n\t"
+                 "s_waitcnt lgkmcnt(0)"
+                 : "=&s"(rc), "=&s"(a0), "=&s"(a1), "=&s"(h)
+                 : "s"(loc), "s"(base), "s"(base1), "s"(hp)
+                 : "memory");
+    head = head_ptr ? h : 0;
+    LocIn in;
+    in.r = rc.x;
+    in.c = rc.y;
+    in.w[0] = a0.x;
+    in.w[1] = wide ? a0.y : 0u;
+    in.w[2] = wide ? a1.x : a0.y;
+    in.w[3] = wide ? a1.y : 0u;
+    return in;
+}
+// ... and the flexible env's extra state (fov_res, sensory_action_type) the same way: six s_loads, one wait (one asm statement:
+// no register of an s_load in flight may be visible to the compiler before the wait)
+__device__ __forceinline__ LocIn load_flex_inputs_scalar(const FovParams &p, int n, int &head, int2 &res_old, int &type) {
+    const bool wide = p.action_dt == AGX_DT_F64 || p.action_dt == AGX_DT_I64;
+    const int32_t *loc = p.loc_in + 2 * n;
+    const char *base = p.action ? static_cast<const char *>(p.action) + (size_t)n * (wide ? 16 : 8)
+                                : reinterpret_cast<const char *>(loc);
+    const char *base1 = base + ((wide && p.action) ? 8 : 0);
+    const int32_t *hp = p.head + n;
+    const int32_t *resp = p.res_in + 2 * n;
+    const int32_t *typp = (p.action && p.action_type) ? p.action_type + n : loc;
+    int2 rc, rs;
+    uint2 a0, a1;
+    int32_t h, ty;
+    asm volatile("s_load_dwordx2 %0, %6, 0x0\n\ts_load_dwordx2 %1, %7, 0x0\n\ts_load_dwordx2 %2, %8, 0x0\n\ts_load_dword %3, %9, 0x0\n\t"
+                 "s_load_dwordx2 %4, %10, 0x0\n\ts_load_dword %5, %11, 0x0\n\t"
+                 "s_waitcnt lgkmcnt(0)"
+                 : "=&s"(rc), "=&s"(a0), "=&s"(a1), "=&s"(h), "=&s"(rs), "=&s"(ty)
+                 : "s"(loc), "s"(base), "s"(base1), "s"(hp), "s"(resp), "s"(typp)
+                 : "memory");
+    head = h;
+    res_old = rs;
+    type = (p.action && p.action_type) ? ty : AGX_FOV_LOC;
+    LocIn in;
+    in.r = rc.x;
+    in.c = rc.y;
+    in.w[0] = a0.x;
+    in.w[1] = wide ? a0.y : 0u;
+    in.w[2] = wide ? a1.x : a0.y;
+    in.w[3] = wide ? a1.y : 0u;
+    return in;
+}
 __device__ __forceinline__ double action_value(int dt, uint32_t lo, uint32_t hi) {
     switch (dt) {
         case AGX_DT_F32: return (double)__uint_as_float(lo);

@@ -112,13 +112,16 @@ __device__ __forceinline__ void fovea_fixed_body(const G g, const FovParams &p, 
     int4 xt = make_int4(0, 0, 0, 0);                                  // this thread's column taps {lo, aux, a, b}
     const int wp = ow;                                                // row pitch of the LDS image
     {
-        const LocIn lin = load_loc_inputs(p, n);
-        const int head = p.head[n] + head_fixup;
+        // this thread's taps go out first (vector loads, in flight through the scalar wait below), then the state through the
+        // scalar cache
         int4 yt0 = make_int4(0, 0, 0, 0);
         if (MODE == AGX_OUT_RESIZE) {
             xt = *reinterpret_cast<const int4 *>(p.xtab + tid % ow);
             yt0 = *reinterpret_cast<const int4 *>(p.ytab + min(tid, oh - 1));
         }
+        int head0;
+        const LocIn lin = load_loc_inputs_scalar(p, n, p.head, head0);
+        const int head = head0 + head_fixup;
         compute_loc(p, lin, oh - fh, ow - fw, r, c);
         r = __builtin_amdgcn_readfirstlane(r);
         c = __builtin_amdgcn_readfirstlane(c);

@@ -67,8 +67,8 @@ __global__ __launch_bounds__(kThreads) void k_fovea_peripheral3(G g, Per3Params 
     int4 *y3_s = reinterpret_cast<int4 *>(lo1_s + ((ph + 3) & ~3));
 
     // ---- every round trip starts now: state, the frame, this thread's taps
-    const LocIn lin = load_loc_inputs(p, n);
-    const int head = p.head[n];
+    int head;
+    const LocIn lin = load_loc_inputs_scalar(p, n, p.head, head);
     const uint32_t *fsrc = reinterpret_cast<const uint32_t *>(p.ring + ((size_t)n * p.fs + sl) * (size_t)fbytes);
     constexpr int kFW = 7;
     uint32_t fw_[kFW];

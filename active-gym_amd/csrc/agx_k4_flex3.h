@@ -92,10 +92,9 @@ __global__ __launch_bounds__(kThreads) void k_fovea_flexible3(G g, Flex3Params t
     int4 *ytab_s = reinterpret_cast<int4 *>(smem + t.r0_bytes + t.r1_bytes);
 
     // ---- the env's state first (vmcnt retires in order: waiting for these leaves the frame loads in flight) ...
-    const LocIn lin = load_loc_inputs(p, n);
-    const int2 res_old = *reinterpret_cast<const int2 *>(p.res_in + 2 * n);
-    const int type = (p.action && p.action_type) ? p.action_type[n] : AGX_FOV_LOC;
-    const int head = p.head[n];
+    int head, type;
+    int2 res_old;
+    const LocIn lin = load_flex_inputs_scalar(p, n, head, res_old, type);     // through the scalar cache: a shorter first hop
     const uint32_t *fsrc = reinterpret_cast<const uint32_t *>(p.ring + ((size_t)n * p.fs + sl) * (size_t)fbytes);
 
     // ---- state update (fov_env.py:300-324); res from agx_set_fov_state is clamped for memory safety only

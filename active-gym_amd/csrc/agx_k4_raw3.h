@@ -156,10 +156,9 @@ __global__ __launch_bounds__(kThreads) void k_fovea_flexible_raw3(G g, FlexRawPa
             if (n == t.n_envs - 1) t.offsets[n + 1] = poff + (int64_t)p.fs * rh * rw;
         }
     } else {
-        const LocIn lin = load_loc_inputs(p, n);
-        const int2 res_old = *reinterpret_cast<const int2 *>(p.res_in + 2 * n);
-        const int type = (p.action && p.action_type) ? p.action_type[n] : AGX_FOV_LOC;
-        head = p.head[n];
+        int type;
+        int2 res_old;
+        const LocIn lin = load_flex_inputs_scalar(p, n, head, res_old, type);
         rh = min(max(res_old.x, 1), oh), rw = min(max(res_old.y, 1), ow);
         if (p.action && type == AGX_FOV_RES) {
             rh = clip_rint(action_value(p.action_dt, lin.w[0], lin.w[1]), 1.0, (double)oh);
