@@ -283,6 +283,33 @@ def test_action_dtypes_and_half_to_even(dev, dtype):
     assert np.array_equal(loc.cpu().numpy(), want)
 
 
+@pytest.mark.parametrize("kind", ["fixed", "flexible"])
+@pytest.mark.parametrize("dtype", [torch.float32, torch.int32, torch.float64])
+def test_action_tensor_at_an_element_aligned_address(dev, kind, dtype):
+    """The env state reaches K2 / K4 through scalar loads (s_load_dwordx2): an action tensor that starts one element into its
+    storage - aligned to its element size only, not to the 8 / 16 bytes of an env's pair - must give what an aligned copy gives."""
+    N = 37
+    rng = np.random.default_rng(5)
+    kw = dict(num_envs=N, kind=kind, obs_size=(84, 84), fov_size=(30, 30), frame_stack=2, resize_to_full=True)
+    a_, b_ = _pipe(**kw), _pipe(**kw)
+    st = _t(rng.integers(0, 256, (N, 2, 84, 84), dtype=np.uint8), dev)
+    a_.set_stack_u8(st); b_.set_stack_u8(st)
+    vals = rng.uniform(-5, 70, (N, 2))
+    flat = torch.zeros(2 * N + 1, dtype=dtype, device=dev)
+    flat[1:] = torch.tensor(vals.reshape(-1), dtype=dtype, device=dev)
+    odd = flat[1:].view(N, 2)                                   # contiguous, data_ptr = storage + one element
+    assert odd.is_contiguous() and odd.data_ptr() % (2 * odd.element_size()) != 0
+    even = odd.clone()
+    extra = {}
+    if kind == "flexible":
+        extra = dict(action_type=_t(rng.integers(0, 2, N).astype(np.int32), dev))
+    ra = a_.fovea(odd, **extra)
+    rb = b_.fovea(even, **extra)
+    for x, y in zip(ra, rb):
+        assert torch.equal(x, y)
+    a_.close(); b_.close()
+
+
 def test_mask_leaves_envs_untouched(dev):
     N = 6
     rng = np.random.default_rng(3)
