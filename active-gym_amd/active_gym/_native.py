@@ -8,7 +8,7 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(os.path.dirname(_HERE), "lib", "libagx.so")
 
-ABI_VERSION = 1
+ABI_VERSION = 2
 
 OK, E_INVALID, E_HIP, E_NOMEM, E_STATE = 0, -1, -2, -3, -4
 KIND_BASE, KIND_FIXED, KIND_FLEXIBLE, KIND_PERIPHERAL = 0, 1, 2, 3
@@ -38,6 +38,7 @@ _P = C.c_void_p
 SIGNATURES = {
     "agx_abi_version": (C.c_int, []),
     "agx_build_info": (C.c_char_p, []),
+    "agx_device_pci_bus_id": (C.c_int, [C.c_int, C.c_char_p, C.c_int]),
     "agx_create": (C.c_int, [C.POINTER(AgxConfig), C.POINTER(_P)]),
     "agx_destroy": (C.c_int, [_P]),
     "agx_last_error": (C.c_char_p, [_P]),
@@ -48,6 +49,9 @@ SIGNATURES = {
     "agx_ingest_gray": (C.c_int, [_P, _P, _P, _P]),
     "agx_ingest_gray_raw": (C.c_int, [_P, _P, _P, _P]),
     "agx_ingest_rgb": (C.c_int, [_P, _P, _P, C.c_int, _P]),
+    "agx_source_rows": (C.c_int, [_P, _P, C.POINTER(C.c_int32)]),
+    "agx_ingest_compact": (C.c_int, [_P, _P, _P, _P]),
+    "agx_ingest_gray_raw_compact": (C.c_int, [_P, _P, _P, _P]),
     "agx_observe_full": (C.c_int, [_P, _P, _P]),
     "agx_get_stack_u8": (C.c_int, [_P, _P, _P]),
     "agx_set_stack_u8": (C.c_int, [_P, _P, _P]),

@@ -24,7 +24,8 @@ class AgxrConfig(C.Structure):
                 ("seed", C.c_int64), ("max_episode_frames", C.c_int32), ("scripted_actions", C.c_int32),
                 ("scripted_lives", C.c_int32), ("scripted_p_life", C.c_int32), ("scripted_p_over", C.c_int32),
                 ("backend", C.c_char_p), ("ale_lib", C.c_char_p), ("rom_path", C.c_char_p),
-                ("gray_frames", C.c_int32), ("reserved", C.c_int32)]
+                ("gray_frames", C.c_int32), ("n_src_rows", C.c_int32), ("src_rows", C.POINTER(C.c_int32)),
+                ("cpu_list", C.POINTER(C.c_int32)), ("n_cpus", C.c_int32), ("reserved", C.c_int32)]
 
 
 _P = C.c_void_p
@@ -39,6 +40,10 @@ SIGNATURES = {
     "agxr_step_wait": (C.c_int, [_P, C.c_int32]),
     "agxr_reset": (C.c_int, [_P, _P, C.c_int32, _P, _P, C.c_int64, _P]),
     "agxr_reset_packed": (C.c_int, [_P, _P, C.c_int32, _P, _P, C.c_int64, _P]),
+    "agxr_default_threads": (C.c_int, []),
+    "agxr_host_cpus": (None, [C.POINTER(C.c_int32 * 3)]),
+    "agxr_num_threads": (C.c_int, [_P]),
+    "agxr_worker_cpu": (C.c_int, [_P, C.c_int32]),
     "agxr_get_state": (C.c_int, [_P, _P, _P]),
     "agxr_render": (C.c_int, [_P, C.c_int32, _P]),
 }
@@ -74,7 +79,10 @@ def _find_libale_c():
 class NativeHostRunner:
     def __init__(self, args, num_envs: int, frames: Optional[np.ndarray] = None, workers: Optional[int] = None,
                  noop_fn: Optional[Callable[[], int]] = None, env_offset: int = 0, backend: str = "scripted",
-                 noop_per_env: bool = False):
+                 noop_per_env: bool = False, src_rows: Optional[Sequence[int]] = None, cpus: Optional[Sequence[int]] = None):
+        """``src_rows``: compact staging - only these screen rows are staged (``ObsPipeline.source_rows()``), every screen
+        in ``frames`` has ``len(src_rows)`` rows.  ``cpus``: worker w is pinned to ``cpus[w % len(cpus)]``
+        (``active_gym.hostplan``).  ``workers`` None / 0: usable CPUs // LOCAL_WORLD_SIZE (agxr_default_threads)."""
         self._lib = lib()
         self.args = args
         self.num_envs = int(num_envs)
@@ -95,6 +103,14 @@ class NativeHostRunner:
         cfg.scripted_p_over = int(getattr(args, "scripted_p_over", 1))
         self.gray = resolve_frame_format(args, real=(backend == "ale_c")) == "gray"
         cfg.gray_frames = int(self.gray)
+        self.src_rows = None if src_rows is None else np.ascontiguousarray(src_rows, dtype=np.int32)
+        if self.src_rows is not None:
+            cfg.n_src_rows = len(self.src_rows)
+            cfg.src_rows = self.src_rows.ctypes.data_as(C.POINTER(C.c_int32))
+        self._cpus = None if not cpus else np.ascontiguousarray(list(cpus), dtype=np.int32)
+        if self._cpus is not None:
+            cfg.n_cpus = len(self._cpus)
+            cfg.cpu_list = self._cpus.ctypes.data_as(C.POINTER(C.c_int32))
         cfg.backend = backend.encode()
         if backend == "ale_c":
             so, atari_py = _find_libale_c()
@@ -107,7 +123,10 @@ class NativeHostRunner:
             raise RuntimeError("agxr_create: " + (self._lib.agxr_last_error(None) or b"").decode())
         self.num_actions = self._lib.agxr_num_actions(self._h)
         self.actions = [list(range(self.num_actions))] * self.num_envs
-        shape = (self.num_envs, 2, RAW_H, RAW_W) + (() if self.gray else (3,))
+        self.num_workers = self._lib.agxr_num_threads(self._h)
+        self.worker_cpus = [self._lib.agxr_worker_cpu(self._h, w) for w in range(self.num_workers)]
+        self.rows = RAW_H if self.src_rows is None else len(self.src_rows)
+        shape = (self.num_envs, 2, self.rows, RAW_W) + (() if self.gray else (3,))
         if frames is None:
             frames = np.zeros(shape, np.uint8)
         assert frames.shape == shape and frames.dtype == np.uint8 and frames.flags.c_contiguous

@@ -150,6 +150,30 @@ class ObsPipeline:
         pc = self._chk(cmd, (self.num_envs,), torch.uint8, "cmd")
         nat.check(self._lib.agx_ingest_gray_raw(self._ctx, pg, pc, self._stream()), self._ctx)
 
+    def source_rows(self) -> np.ndarray:
+        """The screen rows K1 reads (agx_source_rows): the y0 / y1 of cv2.resize's INTER_LINEAR table from 210 to obs rows,
+        ascending - 168 of 210 for 84 rows.  A host runner that stages only these rows feeds :meth:`ingest_compact`."""
+        rows = (C.c_int32 * nat.RAW_H)()
+        n = C.c_int32(0)
+        nat.check(self._lib.agx_source_rows(self._ctx, rows, C.byref(n)), self._ctx)
+        return np.array(rows[:n.value], dtype=np.int32)
+
+    def ingest_compact(self, rows: torch.Tensor, cmd: torch.Tensor):
+        """:meth:`ingest` from compact screens u8[N,2,n_rows,160,3]: row k = screen row ``source_rows()[k]``; same results."""
+        n = len(self.source_rows()) if not hasattr(self, "_n_src") else self._n_src
+        self._n_src = n
+        pf = self._chk(rows, (self.num_envs, 2, n, nat.RAW_W, 3), torch.uint8, "rows")
+        pc = self._chk(cmd, (self.num_envs,), torch.uint8, "cmd")
+        nat.check(self._lib.agx_ingest_compact(self._ctx, pf, pc, self._stream()), self._ctx)
+
+    def ingest_gray_raw_compact(self, rows: torch.Tensor, cmd: torch.Tensor):
+        """:meth:`ingest_gray_raw` from compact grayscale screens u8[N,2,n_rows,160]."""
+        n = len(self.source_rows()) if not hasattr(self, "_n_src") else self._n_src
+        self._n_src = n
+        pg = self._chk(rows, (self.num_envs, 2, n, nat.RAW_W), torch.uint8, "rows")
+        pc = self._chk(cmd, (self.num_envs,), torch.uint8, "cmd")
+        nat.check(self._lib.agx_ingest_gray_raw_compact(self._ctx, pg, pc, self._stream()), self._ctx)
+
     def ingest_gray(self, small: torch.Tensor, cmd: torch.Tensor):
         """small u8[N,2,obs_h,obs_w] already obs-sized gray frames."""
         ps = self._chk(small, (self.num_envs, 2) + self.obs_size, torch.uint8, "small")

@@ -53,7 +53,9 @@ def check_motor_actions(motor, num_actions: int):
 class AtariHostRunner:
     def __init__(self, args, num_envs: int, frames: Optional[np.ndarray] = None,
                  workers: Optional[int] = None, noop_fn: Optional[Callable[[], int]] = None,
-                 env_offset: int = 0, noop_per_env: bool = False):
+                 env_offset: int = 0, noop_per_env: bool = False, src_rows: Optional[Sequence[int]] = None):
+        """``src_rows``: compact staging - only these screen rows are staged (``ObsPipeline.source_rows()``: the rows
+        cv2.resize reads, 168 of 210 for 84 x 84); every screen in ``frames`` then has ``len(src_rows)`` rows."""
         self.args = args
         self.num_envs = int(num_envs)
         self.action_repeat = int(args.action_repeat)
@@ -75,12 +77,19 @@ class AtariHostRunner:
         # frame_format "gray": ALE's own grayscale screens (getScreenGrayscale - what the reference reads,
         # atari_env.py:74) instead of RGB; a third of the bytes, no luminance arithmetic on the device
         self.gray = resolve_frame_format(args) == "gray"
-        shape = (self.num_envs, 2, RAW_H, RAW_W) + (() if self.gray else (3,))
+        self.src_rows = None if src_rows is None else np.asarray(src_rows, dtype=np.intp)
+        self.rows = RAW_H if self.src_rows is None else len(self.src_rows)
+        shape = (self.num_envs, 2, self.rows, RAW_W) + (() if self.gray else (3,))
         if frames is None:
             frames = np.zeros(shape, np.uint8)
         assert frames.shape == shape and frames.dtype == np.uint8
         self.frames = frames
-        n_workers = workers if workers is not None else min(self.num_envs, os.cpu_count() or 1, 64)
+        if workers is None:
+            # the CPUs this process may use (affinity, cgroup quota) shared between the ranks of the node: hostplan.py
+            from .hostplan import read_topology, usable_cpus
+            lws = max(1, int(os.environ.get("LOCAL_WORLD_SIZE", "1") or 1))
+            workers = max(1, min(64, usable_cpus(read_topology()) // lws))
+        n_workers = min(self.num_envs, int(workers))
         self._pool = ThreadPoolExecutor(max_workers=n_workers) if n_workers > 1 else None
         self._n_workers = max(1, n_workers)
 
@@ -104,10 +113,11 @@ class AtariHostRunner:
     def _grab(self, i, slot, buf=None, row=None):
         e = self.emulators[i]
         dst = (self.frames if buf is None else buf)[i if row is None else row, slot]
-        if self.gray:
-            np.copyto(dst, np.asarray(e.getScreenGrayscale()).reshape(RAW_H, RAW_W))
+        scr = np.asarray(e.getScreenGrayscale()).reshape(RAW_H, RAW_W) if self.gray else np.asarray(e.getScreenRGB())
+        if self.src_rows is None:
+            np.copyto(dst, scr)
         else:
-            np.copyto(dst, e.getScreenRGB())
+            np.take(scr, self.src_rows, axis=0, out=dst)
 
     def _map(self, fn, idx: Sequence[int]):
         idx = list(idx)

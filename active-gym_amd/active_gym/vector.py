@@ -166,7 +166,9 @@ class AtariVecEnv:
 
     def _ingest(self, cmd=None):
         cmd = self._d_cmd if cmd is None else cmd
-        if self._gray:
+        if self._compact:
+            (self.pipe.ingest_gray_raw_compact if self._gray else self.pipe.ingest_compact)(self._d_frames, cmd)
+        elif self._gray:
             self.pipe.ingest_gray_raw(self._d_frames, cmd)
         else:
             self.pipe.ingest(self._d_frames, cmd)
@@ -180,7 +182,35 @@ class AtariVecEnv:
         fmt = resolve_frame_format(args)         # real emulators default to ALE's own grayscale screens (atari_env.py:74)
         self._gray = fmt == "gray"
         px = () if self._gray else (3,)
-        shape = (self.num_envs, 2, nat.RAW_H, nat.RAW_W) + px
+        # Compact staging (default; args.compact_rows = False restores whole screens): the runner stages only the screen rows
+        # the vertical resize reads (168 of 210 at 84 x 84 - SURVEY.md 8d's algorithmic bytes already leave the other 42 out),
+        # so a step's H2D copy is 165 MB instead of 206 MB on the PCIe-bound RGB path
+        self._compact = bool(getattr(args, "compact_rows", True))
+        self._src_rows = self.pipe.source_rows() if self._compact else None
+        rows = len(self._src_rows) if self._compact else nat.RAW_H
+        shape = (self.num_envs, 2, rows, nat.RAW_W) + px
+        # Host placement (hostplan.py): this rank's share of the CPUs of its GPU's NUMA node; the pinned staging below is
+        # allocated while bound to them (first touch on that node), the native runner pins one worker per CPU
+        from . import hostplan
+        self.host_plan = hostplan.plan_for_process(self.device.index, workers=getattr(args, "num_workers", None))
+        with hostplan.bound_to(self.host_plan["cpus"] and self.host_plan["domain"]):
+            self._alloc_staging(shape, rows, px)
+        src = getattr(args, "frame_source", "ale")
+        if isinstance(src, str) and src.startswith("native"):
+            # C++ thread-per-core runner (libagx_runner.so): "native" = built-in scripted emulator,
+            # "native:ale" = real ALE through atari_py's libale_c.so
+            from .native_runner import NativeHostRunner
+            self.runner = NativeHostRunner(args, self.num_envs, frames=self._h_frames.numpy(),
+                                           workers=self.host_plan["workers"], noop_fn=noop_fn,
+                                           env_offset=env_offset, backend="ale_c" if src == "native:ale" else "scripted",
+                                           noop_per_env=self._noop_per_env, src_rows=self._src_rows,
+                                           cpus=self.host_plan["cpus"])
+        else:
+            self.runner = AtariHostRunner(args, self.num_envs, frames=self._h_frames.numpy(),
+                                          workers=self.host_plan["workers"], noop_fn=noop_fn,
+                                          env_offset=env_offset, noop_per_env=self._noop_per_env, src_rows=self._src_rows)
+
+    def _alloc_staging(self, shape, rows, px):
         # Two pinned staging sets (screens, command bytes, copy-done event), used alternately: with device outputs step()
         # returns without synchronising, so the emulators of step t+1 fill one set while the H2D copy of step t still
         # drains the other (host-side double buffering; on the device the copies are stream-ordered behind the kernels
@@ -206,25 +236,12 @@ class AtariVecEnv:
         self._d_frames = self._dsets[0]["frames"]
         # reset screens get their own pinned buffer: the autoreset inside step() must not overwrite step
         # screens whose asynchronous H2D copy may still be in flight
-        self._h_rframes = torch.empty((self.num_envs, 1, nat.RAW_H, nat.RAW_W) + px, dtype=torch.uint8, pin_memory=True)
+        self._h_rframes = torch.empty((self.num_envs, 1, rows, nat.RAW_W) + px, dtype=torch.uint8, pin_memory=True)
         self._h_rcmd = torch.empty((self.num_envs,), dtype=torch.uint8, pin_memory=True)
         self._alloc_reset_buffers()
         self._ev_copy = self._stage[0]["ev"]
         self._h_cmd = self._stage[0]["cmd"]
         self._d_cmd = self._dsets[0]["cmd"]
-        src = getattr(args, "frame_source", "ale")
-        if isinstance(src, str) and src.startswith("native"):
-            # C++ thread-per-core runner (libagx_runner.so): "native" = built-in scripted emulator,
-            # "native:ale" = real ALE through atari_py's libale_c.so
-            from .native_runner import NativeHostRunner
-            self.runner = NativeHostRunner(args, self.num_envs, frames=self._h_frames.numpy(),
-                                           workers=getattr(args, "num_workers", None), noop_fn=noop_fn,
-                                           env_offset=env_offset, backend="ale_c" if src == "native:ale" else "scripted",
-                                           noop_per_env=self._noop_per_env)
-        else:
-            self.runner = AtariHostRunner(args, self.num_envs, frames=self._h_frames.numpy(),
-                                          workers=getattr(args, "num_workers", None), noop_fn=noop_fn,
-                                          env_offset=env_offset, noop_per_env=self._noop_per_env)
 
     def _alloc_reset_buffers(self):
         """Staging for resets of a SUBSET of the envs (the autoreset inside step(), reset_envs()).  The runner writes the K reset

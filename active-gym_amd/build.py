@@ -21,6 +21,7 @@ EXP_DEPS = sorted(os.path.join(HERE, "csrc", "experiments", f) for f in os.listd
 OUT_DIR = os.path.join(HERE, "lib")
 OUT = os.path.join(OUT_DIR, "libagx.so")
 EXP_OUT = os.path.join(OUT_DIR, "libagx_exp.so")
+CANARY_OUT = os.path.join(OUT_DIR, "libagx_canary.so")
 
 
 def hipcc():
@@ -66,6 +67,14 @@ def build_experiments(force=False, verbose=False):
     return build(force, verbose, ("-DAGX_EXPERIMENTS",), EXP_OUT, DEPS + EXP_DEPS)
 
 
+def build_canary(force=False, verbose=False):
+    """libagx_canary.so = libagx.so with the KNOWN-BAD observation store of commit 327a14a (an inline-asm
+    `global_store_dwordx4 ... sc1`, whose data VGPRs the next VALU instructions may overwrite: -DAGX_CANARY_ASM_OBS_STORE).
+    Never loaded by the product: tests/test_gpu_lowocc.py runs its own cases against it in a child process and expects them to
+    FAIL there - the proof that those cases see the bug the round-3 kernel tests missed."""
+    return build(force, verbose, ("-DAGX_CANARY_ASM_OBS_STORE",), CANARY_OUT, DEPS)
+
+
 RUNNER_SRC = os.path.join(HERE, "csrc", "agx_runner.cpp")
 RUNNER_OUT = os.path.join(OUT_DIR, "libagx_runner.so")
 
@@ -87,8 +96,10 @@ def build_runner(force=False, verbose=False):
 
 
 if __name__ == "__main__":
-    extra = [a for a in sys.argv[1:] if a.startswith("-") and a not in ("-f", "-v", "--experiments")]
+    extra = [a for a in sys.argv[1:] if a.startswith("-") and a not in ("-f", "-v", "--experiments", "--canary")]
     print(build(force="-f" in sys.argv, verbose=True, extra=extra))
     print(build_runner(force="-f" in sys.argv, verbose=True))
     if "--experiments" in sys.argv:
         print(build_experiments(force="-f" in sys.argv, verbose=True))
+    if "--canary" in sys.argv:
+        print(build_canary(force="-f" in sys.argv, verbose=True))

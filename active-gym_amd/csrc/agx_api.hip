@@ -8,6 +8,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <algorithm>
 #include <new>
 #include <set>
 #include <string>
@@ -33,6 +34,11 @@ struct agx_ctx {
     int2 *in_xtab12 = nullptr; // K1 band12 form: {2 * x0, (a0 | a1 << 16) << 4} / {b0 << 8, b1 << 8}
     int2 *in_ytab12 = nullptr;
     bool band12_ok = false;    // 12-row bands all full, affine source rows, every x tap pair adjacent
+    // compact source screens (agx_ingest_compact): the source rows the vertical resize reads, ascending, and the y table with
+    // PACKED row indices; compact12_ok: band12_ok and every (y0, y1) pair disjoint and ascending (packed rows 2 dy, 2 dy + 1)
+    std::vector<int32_t> src_rows;
+    int4 *in_ytab_c = nullptr;
+    bool compact12_ok = false;
     Tap *fx_xtab = nullptr;    // K2 tables
     Tap *fx_ytab = nullptr;
     int2 *per_ln[4] = {nullptr, nullptr, nullptr, nullptr};   // K3 tables
@@ -341,11 +347,18 @@ const char *agx_build_info(void) { return "libagx abi " AGX_STR(AGX_ABI_VERSION)
 
 const char *agx_last_error(const agx_ctx *ctx) { return ctx ? ctx->err.c_str() : g_create_err.c_str(); }
 
+int agx_device_pci_bus_id(int device, char *buf, int len) {
+    if (!buf || len < 13) return fail(nullptr, AGX_E_INVALID, "agx_device_pci_bus_id: buffer of at least 13 bytes needed");
+    const hipError_t e = hipDeviceGetPCIBusId(buf, len, device);
+    if (e != hipSuccess) return fail(nullptr, AGX_E_HIP, "hipDeviceGetPCIBusId(%d): %s", device, hipGetErrorString(e));
+    return AGX_OK;
+}
+
 int agx_destroy(agx_ctx *ctx) {
     if (!ctx) return AGX_OK;
     DeviceGuard g(ctx->cfg.device);
     void *ptrs[] = {ctx->ring, ctx->head[0], ctx->head[1], ctx->loc[0], ctx->loc[1], ctx->res[0], ctx->res[1],
-                    ctx->in_xtab, ctx->in_ytab, ctx->in_xtab12, ctx->in_ytab12, ctx->fx_xtab, ctx->fx_ytab,
+                    ctx->in_xtab, ctx->in_ytab, ctx->in_ytab_c, ctx->in_xtab12, ctx->in_ytab12, ctx->fx_xtab, ctx->fx_ytab,
                     ctx->per_ln[0], ctx->per_ln[1], ctx->per_ln[2], ctx->per_ln[3],
                     ctx->per_w[0], ctx->per_w[1], ctx->per_w[2], ctx->per_w[3],
                     ctx->flex_ln[0], ctx->flex_ln[1], ctx->flex_ln[2], ctx->flex_ln[3], ctx->flex_ln[4], ctx->flex_ln[5],
@@ -465,6 +478,17 @@ int agx_create(const agx_config *cfg, agx_ctx **out) {
             touched.insert(y1[i]);
         }
         ctx->rows_touched = (int)touched.size();
+        // compact screens: packed index of every touched source row, the y table in packed indices
+        ctx->src_rows.assign(touched.begin(), touched.end());
+        std::vector<int> packed_of(kRawH, -1);
+        for (size_t k = 0; k < ctx->src_rows.size(); ++k) packed_of[ctx->src_rows[k]] = (int)k;
+        std::vector<int4> ytc(c.obs_h);
+        bool pairs = true;
+        for (int i = 0; i < c.obs_h; ++i) {
+            ytc[i] = make_int4(packed_of[y0[i]], packed_of[y1[i]], b0[i], b1[i]);
+            pairs = pairs && ytc[i].x == 2 * i && ytc[i].y == 2 * i + 1;
+        }
+        if ((rc = upload(ctx, &ctx->in_ytab_c, ytc)) != AGX_OK) return bail(rc);
         // look for an exact integer form of the row table: y0 = (dy*mul + add) >> shift, y1 = min(y0+1, H-1)
         for (int sh = 0; sh <= 12 && !ctx->y_affine; ++sh) {
             const long mul = std::lround((double)kRawH / c.obs_h * (double)(1 << sh));
@@ -495,6 +519,7 @@ int agx_create(const agx_config *cfg, agx_ctx **out) {
         if ((rc = upload(ctx, &ctx->in_xtab12, xt12)) != AGX_OK) return bail(rc);
         if ((rc = upload(ctx, &ctx->in_ytab12, yt12)) != AGX_OK) return bail(rc);
         ctx->band12_ok = adjacent && ctx->y_affine && c.obs_h % 12 == 0 && (c.obs_w / 4) * 12 <= kThreads;
+        ctx->compact12_ok = ctx->band12_ok && pairs;
         // ingest workgroup: T threads produce band_rows output rows (band_rows * ow/4 <= T and the
         // 2 * band_rows row jobs fit the T/40 loader groups x 4 iterations).  128-thread workgroups give
         // 16 independent workgroups per CU whose load / compute phases interleave (AGX_INGEST_T tunes).
@@ -698,6 +723,7 @@ static IngestParams ingest_params(agx_ctx *ctx, const uint8_t *d_frames, const u
     p.xtab12 = ctx->in_xtab12;
     p.ytab12 = ctx->in_ytab12;
     p.ow4_inv16 = (65536 + c.obs_w / 4 - 1) / (c.obs_w / 4);
+    p.src_rows = 0;
     p.stamps = nullptr;
 #ifdef AGX_STAMPS
     if (const char *e = getenv("AGX_DBG_PTR")) p.stamps = reinterpret_cast<unsigned long long *>(strtoull(e, nullptr, 0));
@@ -783,6 +809,50 @@ int agx_ingest_gray_raw(agx_ctx *ctx, const uint8_t *d_gray, const uint8_t *d_cm
     AGX_HIP(ctx, hipGetLastError());
     ctx->cur_head ^= 1;
     return AGX_OK;
+}
+
+int agx_source_rows(const agx_ctx *ctx, int32_t *rows, int32_t *n) {
+    if (!ctx || !n) return AGX_E_INVALID;
+    *n = (int32_t)ctx->src_rows.size();
+    if (rows) std::copy(ctx->src_rows.begin(), ctx->src_rows.end(), rows);
+    return AGX_OK;
+}
+
+// agx_ingest / agx_ingest_gray_raw from compact screens: the same band kernels with packed source rows
+static int ingest_compact(agx_ctx *ctx, const uint8_t *d_rows, const uint8_t *d_cmd, void *stream, bool gray, const char *who) {
+    if (!ctx) return AGX_E_INVALID;
+    if (!d_rows || !d_cmd) return fail(ctx, AGX_E_INVALID, "%s: null buffer", who);
+    const agx_config &c = ctx->cfg;
+    if (c.obs_h != c.obs_w)
+        return fail(ctx, AGX_E_INVALID, "%s: obs_size (%d,%d) is not square (cv2.resize takes (width, height): atari_env.py:74)", who,
+                    c.obs_h, c.obs_w);
+    DeviceGuard g(c.device);
+    IngestParams p = ingest_params(ctx, d_rows, d_cmd);
+    p.src_rows = (int32_t)ctx->src_rows.size();
+    p.ytab = ctx->in_ytab_c;             // packed row indices
+    p.y_affine = 0;
+    const int br = std::max(1, std::min(2 * (kThreads / 40), kThreads / (c.obs_w / 4)));
+    p.band_rows = br;
+    p.nbands = (c.obs_h + br - 1) / br;
+    const size_t lds = sizeof(int4) * br + sizeof(int2) * c.obs_w + (size_t)2 * br * 2 * kRawW;
+    const dim3 grid(p.nbands, c.num_envs), block(kThreads);
+    if (ctx->tune.no_full == 0 && ctx->compact12_ok && br == 12) {
+        if (gray) AGX_LAUNCH(0, k_ingest_grayraw_full12_compact, grid, block, band12_lds(ctx), S(stream), p);
+        else AGX_LAUNCH(0, k_ingest_full12_compact, grid, block, band12_lds(ctx), S(stream), p);
+    } else {
+        if (gray) AGX_LAUNCH(0, k_ingest_grayraw_compact, grid, block, lds, S(stream), p);
+        else AGX_LAUNCH(0, k_ingest_compact, grid, block, lds, S(stream), p);
+    }
+    AGX_HIP(ctx, hipGetLastError());
+    ctx->cur_head ^= 1;
+    return AGX_OK;
+}
+
+int agx_ingest_compact(agx_ctx *ctx, const uint8_t *d_rows, const uint8_t *d_cmd, void *stream) {
+    return ingest_compact(ctx, d_rows, d_cmd, stream, false, "agx_ingest_compact");
+}
+int agx_ingest_gray_raw_compact(agx_ctx *ctx, const uint8_t *d_rows, const uint8_t *d_cmd, void *stream) {
+    return ingest_compact(ctx, d_rows, d_cmd, stream, true, "agx_ingest_gray_raw_compact");
 }
 
 int agx_ingest_gray(agx_ctx *ctx, const uint8_t *d_small, const uint8_t *d_cmd, void *stream) {

@@ -110,6 +110,10 @@ struct IngestParams {
     const int2 *xtab12;      // [ow]  {2 * x0 (byte offset of the tap pair in a u16 gray row), (a0 | a1 << 16) << 4}
     const int2 *ytab12;      // [oh]  {b0 << 8, b1 << 8}
     int32_t ow4_inv16;       // ceil(65536 / (ow / 4)): tid / (ow / 4) == (tid * ow4_inv16) >> 16 for tid < 256
+    // COMPACT source screens (agx_ingest_compact): only the src_rows source rows the vertical resize reads, packed in
+    // ascending order - u8 [N][2][src_rows][160][3] (gray: [N][2][src_rows][160]).  `ytab` then holds PACKED row indices;
+    // the band12 form needs every (y0, y1) pair disjoint and ascending, so that output row dy reads packed rows 2 dy, 2 dy + 1.
+    int32_t src_rows;
     unsigned long long *stamps;   // diagnostic builds only (AGX_STAMPS): [workgroup][wave][8] records
 };
 
@@ -125,12 +129,15 @@ struct IngestParams {
 // FBR > 0: compile-time band height with every band full (oh % FBR == 0, 2 * FBR == (T / 40) * 4) and the affine source
 // row form: the row job of iteration `it` is (frame it / 2, row rg + RG * (it % 2)) with no clamping against a ragged
 // last band, so the second frame's offsets are the first's plus a constant and the index arithmetic folds away.
-template <int T, bool GRAY = false, int FBR = 0>
+// COMPACT: the screens hold only the p.src_rows rows the resize reads (packed); p.ytab holds packed row indices and
+// p.y_affine is 0 (rows always come from the table).
+template <int T, bool GRAY = false, int FBR = 0, bool COMPACT = false>
 __device__ __forceinline__ void ingest_band(const IngestParams &p, const int band, const int n, unsigned char *smem,
                                             const int tid) {
     AGX_STAMP(0);
+    static_assert(!(COMPACT && FBR > 0), "the compile-time band form reads full screens");
     constexpr uint32_t kRowB = GRAY ? kRawW : kRawRowBytes;               // source row / frame pitch in bytes
-    constexpr uint32_t kFrameB = kRawH * kRowB;
+    const uint32_t kFrameB = (COMPACT ? (uint32_t)p.src_rows : (uint32_t)kRawH) * kRowB;
     const int BR = FBR > 0 ? FBR : p.band_rows;
     const int dy0 = band * BR;
     const int rows = FBR > 0 ? FBR : min(BR, p.oh - dy0);
@@ -138,7 +145,7 @@ __device__ __forceinline__ void ingest_band(const IngestParams &p, const int ban
     int2 *xtab_s = reinterpret_cast<int2 *>(smem + sizeof(int4) * BR);    // [ow]
     unsigned char *gray = smem + sizeof(int4) * BR + sizeof(int2) * p.ow; // [2][BR][160][2]
     const int ow4 = p.ow >> 2;
-    if (FBR == 0 && !p.y_affine) {           // general geometry: source rows come from the table
+    if (FBR == 0 && (COMPACT || !p.y_affine)) {           // general geometry / compact screens: source rows come from the table
         if (tid < rows) ytab_s[tid] = p.ytab[dy0 + tid];
         __syncthreads();
     }
@@ -175,7 +182,7 @@ __device__ __forceinline__ void ingest_band(const IngestParams &p, const int ban
         const int f = rj >= rows ? 1 : 0;                                 // nvalid <= 2
         const int dyl = rj - f * rows;
         int y0, y1;
-        if (p.y_affine) {
+        if (!COMPACT && p.y_affine) {
             y0 = (int)(mul_u24((uint32_t)(dy0 + dyl), (uint32_t)p.y_mul) + (uint32_t)p.y_add) >> p.y_shift;
             y1 = min(y0 + 1, kRawH - 1);
         } else {
@@ -327,9 +334,9 @@ __device__ __forceinline__ void ingest_band(const IngestParams &p, const int ban
     }
     AGX_STAMP(4);
 }
-template <int T, bool GRAY = false, int FBR = 0>
+template <int T, bool GRAY = false, int FBR = 0, bool COMPACT = false>
 __device__ __forceinline__ void ingest_band(const IngestParams &p, const int band, const int n, unsigned char *smem) {
-    ingest_band<T, GRAY, FBR>(p, band, n, smem, (int)threadIdx.x);
+    ingest_band<T, GRAY, FBR, COMPACT>(p, band, n, smem, (int)threadIdx.x);
 }
 
 
@@ -382,14 +389,16 @@ constexpr uint32_t kB12FrameB = kB12Rows * kB12JobB;
 constexpr uint32_t kB12GrayB = 2 * kB12FrameB;                            // 15,360 B
 
 // LDS: ytab12[12] int2 | xtab12[ow] int2 | gray16 [2][12][2][160] u16
-template <bool GRAY>
+// COMPACT: packed source rows (see IngestParams::src_rows): output row dy reads packed rows 2 dy and 2 dy + 1 - no row
+// arithmetic at all, and every byte of every 128-B line the kernel touches is used.
+template <bool GRAY, bool COMPACT = false>
 __device__ __forceinline__ void ingest_band12(const IngestParams &p, const int band, const int n, unsigned char *smem,
                                               const int tid) {
     constexpr int T = kThreads;
     (void)T;
     AGX_STAMP(0);
     constexpr uint32_t kRowB = GRAY ? kRawW : kRawRowBytes;
-    constexpr uint32_t kFrameB = kRawH * kRowB;
+    const uint32_t kFrameB = (COMPACT ? (uint32_t)p.src_rows : (uint32_t)kRawH) * kRowB;
     constexpr int G4 = kRawW / 4, RG = kThreads / G4;                     // 40 pieces per row, 6 row groups
     const int dy0 = band * kB12Rows;
     int2 *ytab_s = reinterpret_cast<int2 *>(smem);
@@ -409,8 +418,8 @@ __device__ __forceinline__ void ingest_band12(const IngestParams &p, const int b
 #pragma unroll
         for (int itl = 0; itl < 2; ++itl) {
             const uint32_t dy = (uint32_t)(dy0 + rg + RG * itl);
-            const int y0 = (int)(mul_u24(dy, (uint32_t)p.y_mul) + (uint32_t)p.y_add) >> p.y_shift;
-            const int y1 = min(y0 + 1, kRawH - 1);
+            const int y0 = COMPACT ? (int)(2u * dy) : (int)(mul_u24(dy, (uint32_t)p.y_mul) + (uint32_t)p.y_add) >> p.y_shift;
+            const int y1 = COMPACT ? y0 + 1 : min(y0 + 1, kRawH - 1);
             o0[itl] = mad_u24((uint32_t)y0, kRowB, col);
             o1[itl] = mad_u24((uint32_t)y1, kRowB, col);
         }
@@ -570,6 +579,24 @@ __global__ __launch_bounds__(T) void k_ingest(IngestParams p) {
 __global__ __launch_bounds__(kThreads) void k_ingest_full12(IngestParams p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     ingest_band12<false>(p, blockIdx.x, blockIdx.y, smem, (int)threadIdx.x);
+}
+
+// compact source screens (agx_ingest_compact / agx_ingest_gray_raw_compact)
+__global__ __launch_bounds__(kThreads) void k_ingest_full12_compact(IngestParams p) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    ingest_band12<false, true>(p, blockIdx.x, blockIdx.y, smem, (int)threadIdx.x);
+}
+__global__ __launch_bounds__(kThreads) void k_ingest_compact(IngestParams p) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    ingest_band<kThreads, false, 0, true>(p, blockIdx.x, blockIdx.y, smem);
+}
+__global__ __launch_bounds__(kThreads) void k_ingest_grayraw_full12_compact(IngestParams p) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    ingest_band12<true, true>(p, blockIdx.x, blockIdx.y, smem, (int)threadIdx.x);
+}
+__global__ __launch_bounds__(kThreads) void k_ingest_grayraw_compact(IngestParams p) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    ingest_band<kThreads, true, 0, true>(p, blockIdx.x, blockIdx.y, smem);
 }
 
 // K1g: the same from ALE grayscale screens u8 [N][2][210][160] (agx_ingest_gray_raw)

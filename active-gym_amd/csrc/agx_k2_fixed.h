@@ -24,6 +24,9 @@ namespace agx {
 // resource per workgroup = its output frame: the pointer is wave-uniform by construction, out-of-range offsets are dropped.
 struct ObsOut {
     __amdgpu_buffer_rsrc_t rs;
+#ifdef AGX_CANARY_ASM_OBS_STORE
+    float4 *base;
+#endif
 };
 __device__ __forceinline__ ObsOut obs_out(float4 *frame, int n_float4) {
     const uintptr_t a = reinterpret_cast<uintptr_t>(frame);
@@ -31,12 +34,25 @@ __device__ __forceinline__ ObsOut obs_out(float4 *frame, int n_float4) {
     void *p = reinterpret_cast<void *>(((uintptr_t)hi << 32) | lo);
     ObsOut o;
     o.rs = __builtin_amdgcn_make_buffer_rsrc(p, 0, n_float4 * 16, 0x00027000);
+#ifdef AGX_CANARY_ASM_OBS_STORE
+    o.base = frame;
+#endif
     return o;
 }
 __device__ __forceinline__ void store_obs(const ObsOut &o, int q, const float4 &v) {
+#ifdef AGX_CANARY_ASM_OBS_STORE
+    // The KNOWN-BAD store of commit 327a14a, kept as a canary for the tests only (build.py: build_canary() ->
+    // lib/libagx_canary.so, never loaded by the product): an inline-asm store is invisible to the compiler's hazard
+    // recogniser, and on gfx940+ the data VGPRs of a store of more than 64 bits must not be overwritten by the VALU
+    // instructions right behind it.  tests/test_gpu_lowocc.py must FAIL on this build (tools/canary_probe.py shows it).
+    typedef float f4v __attribute__((ext_vector_type(4)));
+    const f4v w = {v.x, v.y, v.z, v.w};
+    asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(o.base + q), "v"(w));
+#else
     typedef uint32_t u4v __attribute__((ext_vector_type(4)));
     const u4v w = {__float_as_uint(v.x), __float_as_uint(v.y), __float_as_uint(v.z), __float_as_uint(v.w)};
     __builtin_amdgcn_raw_buffer_store_b128(w, o.rs, q * 16, 0, 16 /* sc1 */);
+#endif
 }
 
 // one float of a raw crop (fixed: [fh][fw]; flexible, packed: [rh][rw] at an arbitrary 4-byte aligned offset - hence dword stores),

@@ -2,6 +2,8 @@
 #include "agx_runner.h"
 
 #include <dlfcn.h>
+#include <pthread.h>
+#include <sched.h>
 
 #include <algorithm>
 #include <atomic>
@@ -9,7 +11,9 @@
 #include <condition_variable>
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
+#include <fstream>
 #include <functional>
 #include <memory>
 #include <mutex>
@@ -31,6 +35,18 @@ struct Emulator {
     virtual void screen_rgb(uint8_t *out) = 0; // [210][160][3]
     virtual void screen_gray(uint8_t *out) = 0; // [210][160]  ALE getScreenGrayscale
     virtual std::vector<int> minimal_actions() = 0;
+    // compact staging (agxr_config.src_rows): only the n listed screen rows, packed -> out [n][160][3] / [n][160].  Default: the
+    // whole screen into a per-thread scratch buffer (cache-resident), then the wanted rows
+    virtual void screen_rgb_rows(uint8_t *out, const int32_t *rows, int n) {
+        thread_local std::vector<uint8_t> full((size_t)kFrameBytes);
+        screen_rgb(full.data());
+        for (int k = 0; k < n; ++k) std::memcpy(out + (size_t)k * kW * 3, full.data() + (size_t)rows[k] * kW * 3, (size_t)kW * 3);
+    }
+    virtual void screen_gray_rows(uint8_t *out, const int32_t *rows, int n) {
+        thread_local std::vector<uint8_t> full((size_t)kH * kW);
+        screen_gray(full.data());
+        for (int k = 0; k < n; ++k) std::memcpy(out + (size_t)k * kW, full.data() + (size_t)rows[k] * kW, (size_t)kW);
+    }
 };
 
 // ---- "scripted": splitmix64 event script, arithmetic screens; mirrored by tests/lcg_ale.py ----------------
@@ -74,21 +90,28 @@ struct ScriptedEmu final : Emulator {
         ++episode;
         frame = 0;
     }
-    void screen_rgb(uint8_t *out) override {
-        const uint32_t K = (uint32_t)((seed * 1000003ull + (uint64_t)episode * 7919ull + (uint64_t)frame * 31ull) & 0xFFFFu);
-        for (int y = 0; y < kH; ++y)
-            for (int x = 0; x < kW; ++x) {
-                const uint32_t base = (uint32_t)(y * 7 + x * 13) + K * 3u + (uint32_t)((y * x) >> 4);
-                uint8_t *p = out + ((size_t)y * kW + x) * 3;
-                p[0] = (uint8_t)(base & 0xFF);
-                p[1] = (uint8_t)((base + 29u) & 0xFF);
-                p[2] = (uint8_t)((base + 58u + (K >> 3)) & 0xFF);
-            }
+    uint32_t screen_key() const {
+        return (uint32_t)((seed * 1000003ull + (uint64_t)episode * 7919ull + (uint64_t)frame * 31ull) & 0xFFFFu);
     }
-    void screen_gray(uint8_t *out) override {                 // what ALE's palette would give for these RGB values
-        const uint32_t K = (uint32_t)((seed * 1000003ull + (uint64_t)episode * 7919ull + (uint64_t)frame * 31ull) & 0xFFFFu);
+    static void rgb_row(uint32_t K, int y, uint8_t *row) {
+        for (int x = 0; x < kW; ++x) {
+            const uint32_t base = (uint32_t)(y * 7 + x * 13) + K * 3u + (uint32_t)((y * x) >> 4);
+            uint8_t *p = row + (size_t)x * 3;
+            p[0] = (uint8_t)(base & 0xFF);
+            p[1] = (uint8_t)((base + 29u) & 0xFF);
+            p[2] = (uint8_t)((base + 58u + (K >> 3)) & 0xFF);
+        }
+    }
+    void screen_rgb(uint8_t *out) override {
+        const uint32_t K = screen_key();
+        for (int y = 0; y < kH; ++y) rgb_row(K, y, out + (size_t)y * kW * 3);
+    }
+    void screen_rgb_rows(uint8_t *out, const int32_t *rows, int n) override {      // only the wanted rows are generated at all
+        const uint32_t K = screen_key();
+        for (int k = 0; k < n; ++k) rgb_row(K, rows[k], out + (size_t)k * kW * 3);
+    }
+    static void gray_lut(uint32_t K, uint8_t *lut) {
         // r, g, b are functions of (base & 0xFF) for a given K: one 256-entry table per screen, like ALE's palette
-        uint8_t lut[256];
         for (uint32_t v8 = 0; v8 < 256; ++v8) {
             const uint32_t r = v8, g = (v8 + 29u) & 0xFF, b = (v8 + 58u + (K >> 3)) & 0xFF;
             // round(.2989 r + .5870 g + .1140 b): the rational value decides, except on exact .5 ties, where
@@ -102,13 +125,24 @@ struct ScriptedEmu final : Emulator {
             }
             lut[v8] = (uint8_t)q;
         }
-        for (int y = 0; y < kH; ++y) {
-            uint8_t idx[kW];                                   // the index arithmetic vectorises; the table walk follows
-            for (int x = 0; x < kW; ++x)
-                idx[x] = (uint8_t)((uint32_t)(y * 7 + x * 13) + K * 3u + (uint32_t)((y * x) >> 4));
-            uint8_t *row = out + (size_t)y * kW;
-            for (int x = 0; x < kW; ++x) row[x] = lut[idx[x]];
-        }
+    }
+    static void gray_row(uint32_t K, const uint8_t *lut, int y, uint8_t *row) {
+        uint8_t idx[kW];                                       // the index arithmetic vectorises; the table walk follows
+        for (int x = 0; x < kW; ++x)
+            idx[x] = (uint8_t)((uint32_t)(y * 7 + x * 13) + K * 3u + (uint32_t)((y * x) >> 4));
+        for (int x = 0; x < kW; ++x) row[x] = lut[idx[x]];
+    }
+    void screen_gray(uint8_t *out) override {                 // what ALE's palette would give for these RGB values
+        const uint32_t K = screen_key();
+        uint8_t lut[256];
+        gray_lut(K, lut);
+        for (int y = 0; y < kH; ++y) gray_row(K, lut, y, out + (size_t)y * kW);
+    }
+    void screen_gray_rows(uint8_t *out, const int32_t *rows, int n) override {
+        const uint32_t K = screen_key();
+        uint8_t lut[256];
+        gray_lut(K, lut);
+        for (int k = 0; k < n; ++k) gray_row(K, lut, rows[k], out + (size_t)k * kW);
     }
     std::vector<int> minimal_actions() override {
         std::vector<int> v(n_actions);
@@ -175,9 +209,21 @@ struct AleEmu final : Emulator {
 // ---- a small persistent thread pool: start(fn) calls fn(worker, nworkers) on every worker, wait() joins ---
 class Pool {
   public:
-    explicit Pool(int n) : n_(n) {
-        for (int i = 0; i < n_; ++i) threads_.emplace_back([this, i] { loop(i); });
+    // cpus: worker i is pinned to cpus[i % cpus.size()] (empty: not pinned)
+    explicit Pool(int n, const std::vector<int> &cpus = {}) : n_(n) {
+        for (int i = 0; i < n_; ++i) {
+            threads_.emplace_back([this, i] { loop(i); });
+            int cpu = -1;
+            if (!cpus.empty()) {
+                cpu_set_t set;
+                CPU_ZERO(&set);
+                CPU_SET(cpus[i % cpus.size()], &set);
+                if (pthread_setaffinity_np(threads_.back().native_handle(), sizeof set, &set) == 0) cpu = cpus[i % cpus.size()];
+            }
+            cpu_.push_back(cpu);
+        }
     }
+    int cpu_of(int w) const { return w >= 0 && w < (int)cpu_.size() ? cpu_[w] : -1; }
     ~Pool() {
         wait();
         {
@@ -230,6 +276,7 @@ class Pool {
         }
     }
     int n_;
+    std::vector<int> cpu_;
     std::vector<std::thread> threads_;
     std::mutex m_;
     std::condition_variable cv_, done_;
@@ -241,10 +288,44 @@ class Pool {
 
 thread_local std::string g_create_err;
 
+// CPUs this process may use: the scheduler affinity mask, the cgroup CPU quota (v2 cpu.max, v1 cfs_quota_us / cfs_period_us)
+void host_cpus(int &affinity, double &quota, int &local_world) {
+    cpu_set_t set;
+    CPU_ZERO(&set);
+    affinity = sched_getaffinity(0, sizeof set, &set) == 0 ? CPU_COUNT(&set) : (int)std::thread::hardware_concurrency();
+    if (affinity < 1) affinity = 1;
+    quota = 0.0;
+    {
+        std::ifstream f("/sys/fs/cgroup/cpu.max");
+        std::string a, b;
+        if (f >> a >> b) {
+            if (a != "max") quota = std::atof(a.c_str()) / std::max(1.0, std::atof(b.c_str()));
+        } else {
+            std::ifstream q("/sys/fs/cgroup/cpu/cpu.cfs_quota_us"), per("/sys/fs/cgroup/cpu/cpu.cfs_period_us");
+            double qv = 0, pv = 0;
+            if ((q >> qv) && (per >> pv) && qv > 0 && pv > 0) quota = qv / pv;
+        }
+    }
+    const char *lw = std::getenv("LOCAL_WORLD_SIZE");
+    local_world = lw && std::atoi(lw) > 0 ? std::atoi(lw) : 1;
+}
+
+int default_threads() {
+    int aff, lw;
+    double quota;
+    host_cpus(aff, quota, lw);
+    int usable = aff;
+    if (quota > 0.0) usable = std::max(1, std::min(aff, (int)(quota + 0.5)));
+    return std::max(1, std::min(64, usable / lw));
+}
+
 }  // namespace
 
 struct agxr_runner {
     agxr_config cfg;
+    std::vector<int32_t> src_rows;           // compact staging: the staged screen rows (empty: whole screens)
+    std::vector<int> cpus;                   // worker placement (empty: not pinned)
+    size_t screen_bytes = 0;                 // one staged screen
     std::vector<std::unique_ptr<Emulator>> emu;
     std::vector<std::vector<int>> actions;   // per env: index -> emulator action (atari_env.py:51-52)
     std::vector<int32_t> lives;
@@ -312,16 +393,56 @@ int agxr_create(const agxr_config *cfg, agxr_runner **out) {
     }
     r->lives.assign(cfg->num_envs, 0);
     r->life_termination.assign(cfg->num_envs, 0);
-    // default: one worker per host core, but no more than 64 (measured on a 256-thread host: 64 workers step 1024 envs
-    // fastest; beyond that wake-up and cache traffic cost more than the extra cores give)
-    int nt = cfg->num_threads > 0 ? cfg->num_threads : std::min(64, (int)std::thread::hardware_concurrency());
+    if (cfg->n_src_rows < 0 || cfg->n_src_rows > kH || (cfg->n_src_rows > 0 && !cfg->src_rows))
+        return fail(nullptr, AGXR_E_INVALID, "agxr_create: n_src_rows %d needs a list of at most %d rows", cfg->n_src_rows, kH);
+    for (int k = 0; k < cfg->n_src_rows; ++k) {
+        const int y = cfg->src_rows[k];
+        if (y < 0 || y >= kH || (k > 0 && y <= cfg->src_rows[k - 1]))
+            return fail(nullptr, AGXR_E_INVALID, "agxr_create: src_rows must be ascending rows in [0, %d)", kH);
+        r->src_rows.push_back(y);
+    }
+    r->cfg.src_rows = nullptr;               // (the caller's list is not kept)
+    r->screen_bytes = (size_t)(r->src_rows.empty() ? kH : (int)r->src_rows.size()) * kW * (cfg->gray_frames ? 1 : 3);
+    if (cfg->n_cpus < 0 || (cfg->n_cpus > 0 && !cfg->cpu_list)) return fail(nullptr, AGXR_E_INVALID, "agxr_create: bad cpu_list");
+    for (int k = 0; k < cfg->n_cpus; ++k) {
+        if (cfg->cpu_list[k] < 0 || cfg->cpu_list[k] >= CPU_SETSIZE) return fail(nullptr, AGXR_E_INVALID, "agxr_create: cpu %d out of range", cfg->cpu_list[k]);
+        r->cpus.push_back(cfg->cpu_list[k]);
+    }
+    r->cfg.cpu_list = nullptr;
+    // default: the CPUs this process may use (affinity, cgroup quota) / LOCAL_WORLD_SIZE - one process per GPU shares the host with
+    // its sibling ranks - and no more than 64 (measured on a 256-thread host: 64 workers step 1024 envs fastest; beyond that
+    // wake-up and cache traffic cost more than the extra cores give)
+    int nt = cfg->num_threads > 0 ? cfg->num_threads : default_threads();
     nt = std::max(1, std::min(nt, cfg->num_envs));
-    r->pool = std::make_unique<Pool>(nt);
+    r->pool = std::make_unique<Pool>(nt, r->cpus);
     *out = r.release();
     return AGXR_OK;
 }
 
 int agxr_num_actions(const agxr_runner *r) { return r ? (int)r->actions[0].size() : AGXR_E_INVALID; }
+
+int agxr_default_threads(void) { return default_threads(); }
+void agxr_host_cpus(int32_t out[3]) {
+    int aff, lw;
+    double quota;
+    host_cpus(aff, quota, lw);
+    out[0] = aff;
+    out[1] = (int32_t)(quota + 0.5);
+    out[2] = lw;
+}
+int agxr_num_threads(const agxr_runner *r) { return r ? r->pool->size() : AGXR_E_INVALID; }
+int agxr_worker_cpu(const agxr_runner *r, int32_t w) { return r ? r->pool->cpu_of(w) : -1; }
+
+// one screen of emulator e into the staging layout of this runner (whole or compact, RGB or gray)
+static inline void grab(const agxr_runner *r, Emulator &e, uint8_t *dst) {
+    const bool gray = r->cfg.gray_frames != 0;
+    if (r->src_rows.empty()) {
+        if (gray) e.screen_gray(dst); else e.screen_rgb(dst);
+    } else {
+        if (gray) e.screen_gray_rows(dst, r->src_rows.data(), (int)r->src_rows.size());
+        else e.screen_rgb_rows(dst, r->src_rows.data(), (int)r->src_rows.size());
+    }
+}
 
 void agxr_set_training(agxr_runner *r, int training) {
     if (r) r->training = training != 0;
@@ -333,16 +454,15 @@ static void step_env(agxr_runner *r, int i, const int32_t *motor, uint8_t *frame
     const int a = r->actions[i][motor[i]];
     int rew = 0, nvalid = 0;
     bool d = false;
-    const size_t fb = r->cfg.gray_frames ? (size_t)kH * kW : (size_t)kFrameBytes;
-    const bool gray = r->cfg.gray_frames != 0;
+    const size_t fb = r->screen_bytes;
     uint8_t *f = frames + (size_t)i * 2 * fb;
     for (int t = 0; t < r->cfg.action_repeat; ++t) {          // atari_env.py:123-131
         rew += e.act(a);
         if (t == 2) {
-            if (gray) e.screen_gray(f); else e.screen_rgb(f);
+            grab(r, e, f);
             nvalid = 1;
         } else if (t == 3) {
-            if (gray) e.screen_gray(f + fb); else e.screen_rgb(f + fb);
+            grab(r, e, f + fb);
             nvalid = 2;
         }
         d = e.game_over();
@@ -448,8 +568,7 @@ static int reset_impl(agxr_runner *r, const int32_t *idx, int32_t k, const int32
                 if (e.game_over()) e.reset_game();
             }
             uint8_t *dst = frames + (size_t)(packed ? j : i) * env_stride;    // packed: the j-th reset env's screen in row j
-            if (r->cfg.gray_frames) e.screen_gray(dst);
-            else e.screen_rgb(dst);
+            grab(r, e, dst);
             r->lives[i] = e.lives();
             cmd[i] = (uint8_t)(1 | clear);
         }

@@ -54,11 +54,13 @@ def parse():
                          "first millisecond of an idle device (clock ramp); not part of `warmup` or `steps`")
     ap.add_argument("--samples", type=int, default=24,
                     help="launch pairs carrying their own HIP events in the sampling pass that FOLLOWS the timed region")
-    ap.add_argument("--fused", action="store_true",
-                    help="fixed kind: use agx_step_fixed's heterogeneous launch (sets AGX_STEP_FUSED=1; measured a tie)")
-    ap.add_argument("--split", action="store_true",
-                    help="fixed kind: agx_step_fixed's split step (AGX_STEP_SPLIT env-range parts on internal streams: one "
-                         "part's stores under another part's loads; measured slower than the two stand-alone launches)")
+    ap.add_argument("--obs-pool", type=int, default=3,
+                    help="second sampling pass of the fovea kernel with its output rotating through this many observation "
+                         "buffers (3 x 115.6 MB no longer fits the 256 MB Infinity Cache: `kernels_obs_pool` is the kernel "
+                         "against HBM, `kernels` the product's double-buffered form); 0 = skip")
+    ap.add_argument("--compact", action="store_true",
+                    help="time the step on COMPACT input screens (only the 168 of 210 rows K1 reads, agx_ingest_compact: what the "
+                         "host runner stages) instead of whole screens; the default run reports it beside `value` as `compact_input`")
     ap.add_argument("--event-mode", default="kernel", choices=("kernel", "stream"),
                     help="kernel: start/stop HIP events stamped by the launch itself (hipExtLaunchKernelGGL through "
                          "agx_profile_next: the kernel's own begin/end, what rocprofv3 reports); stream: events recorded "
@@ -86,6 +88,25 @@ def synth_inputs(torch, dev, n, pool, seed, gray=False):
         cmds.append(cmd.contiguous())
         acts.append((torch.rand((n, 2), device=dev, generator=g) * 65.0 - 5.0).contiguous())
     return frames, cmds, acts
+
+
+def workload_name(args, n, packed_mode, gray, compact):
+    """config.workload: which BASELINE.json config this run is (configs[1] = the metric's; [2] / [3] = the peripheral / flexible
+    sub-runs of SURVEY.md 8d)."""
+    which = {"fixed": ("AtariFixedFovealEnv", "configs[1]"), "peripheral": ("AtariFixedFovealPeripheralEnv, peripheral_res 20x20", "configs[2]"),
+             "flexible": ("AtariFlexibleFovealEnv, per-env fov_res in [10,60]^2, 50% FOV_RES actions", "configs[3]")}[args.kind]
+    s = f"{n}x {which[0]} per GPU, 84x84 obs, 30x30 fov, frame_stack=4, action_repeat=4, "
+    s += "ragged raw crops packed (agx_fovea_flexible_packed)" if packed_mode else "resize_to_full"
+    if args.kind != "fixed":
+        s += f", antialias={args.antialias}"
+    s += ", absolute sensory actions; "
+    if gray:
+        s += "device-resident synthetic GRAY screens (getScreenGrayscale format) - NOT the metric's workload"
+    else:
+        s += f"device-resident synthetic RGB frames (BASELINE.json {which[1]}" + (", the ragged-raw sub-run)" if packed_mode else ")")
+    if compact:
+        s += "; compact input screens (--compact)"
+    return s
 
 
 def make_pipeline(kind, n, dev, antialias=True, packed=False):
@@ -261,8 +282,10 @@ def run_e2e(dev, n, hc):
     # emulator threads: twice the cores this job may use (affinity and cgroup quota), at most 64.  The scripted emulator's threads
     # mostly wait on screen writes to pinned memory; measured on a 16-core quota (tools/e2e_workers.py, N = 1024): 16 threads
     # 0.228 M / 0.644 M env steps/s (RGB / gray screens), 32 threads 0.269 M / 0.770 M, 64 threads 0.267 M / 0.779 M
-    workers = max(1, min(64, 2 * hc["usable"]))
+    lws = max(1, int(os.environ.get("LOCAL_WORLD_SIZE", "1") or 1))            # one process per GPU shares the host with its siblings
+    workers = max(1, min(64, 2 * hc["usable"] // lws))
     out = {"envs": n, "runner": "libagx_runner.so (C++ threads, scripted emulator)", "workers": workers, "h2d_chunk_envs": 0,
+           "local_world_size": lws,
            "overlap": "double-buffered pinned staging: the emulators of step t+1 run under the H2D copy and kernels of step t",
            "host_cores_usable": hc["usable"], "host_cores_present": hc["present"],
            "resets": "scripted life-loss / game-over events at 6 / 1 per mille per emulator frame: done envs are reset inside the "
@@ -284,6 +307,10 @@ def run_e2e(dev, n, hc):
                             sensory_action_mode="absolute", resize_to_full=True, frame_source="native", device=str(dev),
                             num_workers=workers, h2d_chunk_envs=0, scripted_lives=3, scripted_p_life=6, scripted_p_over=1)
         env = AtariVecEnv(args, n, kind="fixed")
+        plan = env.host_plan
+        out["placement"] = {"numa_node": plan["numa_node"], "workers": env.runner.num_workers, "pinned_cpus": sorted(set(env.runner.worker_cpus)),
+                            "cpus_usable": plan["usable"], "per_rank_default": plan["per_rank"],
+                            "staging": "pinned buffers allocated while bound to the rank's CPUs (first touch on the GPU's NUMA node)"}
         env.reset()
         env.step(act)
         times, dones = [], 0
@@ -294,11 +321,13 @@ def run_e2e(dev, n, hc):
                 dones += int(env.step(act)[2].sum())
             torch.cuda.synchronize(dev)
             times.append((time.perf_counter() - t0) / steps)
+        bytes_step = int(env._h_frames.numel())          # compact staging: only the rows K1 reads cross PCIe
+        rows_staged = int(env._h_frames.shape[2])
         env.close()
         best, med = min(times), sorted(times)[1]
-        bytes_step = n * 2 * 210 * 160 * (3 if fmt == "rgb" else 1)
         out[fmt] = {"ms_per_step": best * 1e3, "env_steps_per_s": n / best, "env_steps_per_s_median": n / med,
-                    "h2d_bytes_per_step": bytes_step, "pcie_GBps_effective": bytes_step / best / 1e9, "steps_timed": steps,
+                    "h2d_bytes_per_step": bytes_step, "rows_staged_per_screen": rows_staged,
+                    "pcie_GBps_effective": bytes_step / best / 1e9, "steps_timed": steps,
                     "repeats": 3, "reset_fraction": dones / (3.0 * steps * n)}
     return out
 
@@ -316,20 +345,21 @@ def pmc_traffic(kernel, n_envs, kind):
         return None, "profile exists for 1024 envs per GPU only"
     files = sorted(glob.glob(os.path.join(REPO, "profiles", "r*_traffic*.json")))
     files = [f for f in files if not f.endswith(f"_{kind}.json")] + [f for f in files if f.endswith(f"_{kind}.json")]
-    why = "no profiles/r*_traffic*.json"
+    why = None
     for f in reversed(files):                   # newest round first, the file collected under this --kind before the others
         try:
             prof = json.load(open(f))
             e = prof["kernels"][kernel]
             if prof.get("build") != nat.build_info():
-                why = f"{os.path.relpath(f, REPO)} was collected on '{prof.get('build')}', this library is '{nat.build_info()}': stale, not quoted"
+                if why is None:                 # name the NEWEST profile that does not match, not the oldest
+                    why = f"{os.path.relpath(f, REPO)} was collected on '{prof.get('build')}', this library is '{nat.build_info()}': stale, not quoted"
                 continue
             return {"traffic": float(e["traffic"]),
                     "note": f"{os.path.relpath(f, REPO)} ({e.get('kernel_name', kernel)}; build {prof['build']}): FETCH_SIZE x "
                             f"{e['fetch_factor_used']:.3f} + WRITE_SIZE, separate --pmc passes"}, None
         except (KeyError, ValueError, OSError, TypeError):
             continue
-    return None, why
+    return None, why or "no profiles/r*_traffic*.json"
 
 
 def barrier(dist, local_rank):
@@ -373,8 +403,6 @@ def relaunch_under_torchrun(args):
 
 def main():
     args = parse()
-    if args.fused:
-        os.environ.setdefault("AGX_STEP_FUSED", "1")        # per-context tuning knob, read in agx_create
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -404,7 +432,18 @@ def main():
     pipe = make_pipeline(args.kind, n, dev, antialias=bool(args.antialias), packed=packed_mode)
     gray = args.frame_format == "gray"
     frames, cmds, acts = synth_inputs(torch, dev, n, args.pool, 1234 + rank, gray)
-    ingest = pipe.ingest_gray_raw if gray else pipe.ingest
+    ingest_full = pipe.ingest_gray_raw if gray else pipe.ingest
+    ingest_compact = pipe.ingest_gray_raw_compact if gray else pipe.ingest_compact
+    src_rows = torch.from_numpy(pipe.source_rows()).to(dev).long()
+
+    def compact_pool():
+        """The same synthetic screens in the runner's compact staging layout: only the rows K1 reads, packed."""
+        return [f.index_select(2, src_rows).contiguous() for f in frames]
+
+    use_compact = bool(args.compact)
+    if use_compact:
+        frames = compact_pool()
+    ingest = ingest_compact if use_compact else ingest_full
     types = None
     if args.kind == "flexible":
         g = torch.Generator(device=dev)
@@ -421,19 +460,15 @@ def main():
         packed_buf = torch.empty((n * pipe.frame_stack * 60 * 60,), dtype=torch.float32, device=dev)
         offsets = torch.empty((n + 1,), dtype=torch.int64, device=dev)
 
-    fused = args.kind == "fixed" and args.fused and os.environ.get("AGX_STEP_FUSED") is not None
-    # --split: agx_step_fixed's split step; the sampled steps still run as two stand-alone full-batch launches carrying
-    # their own HIP events - the per-kernel roofline is a solo figure
-    split = args.kind == "fixed" and not gray and not fused and (args.split or os.environ.get("AGX_STEP_ENV"))
-
-    kernel_events = args.event_mode == "kernel" and not fused
+    kernel_events = args.event_mode == "kernel"
     issued = {"events": 0}          # HIP events handed to launches / recorded on the stream, counted per phase below
+    state = {"ingest": ingest, "frames": frames, "obs": [obs]}      # what step() runs on (the later legs swap these)
 
     def step(k, e=None):
         """One pass of the hot path over batch k of the pool; `e` = the HIP events of a sampled step: 4 stamped by
         its two launches themselves (kernel mode) or 3 recorded on the stream around them (stream mode)."""
         i = k % args.pool
-        sampled = e is not None
+        out = state["obs"][k % len(state["obs"])]
         if e is not None:
             issued["events"] += len(e)
         if e is not None and kernel_events:
@@ -442,21 +477,15 @@ def main():
             e = None
         if e is not None:
             e[0].record()
-        if split and not sampled:
-            pipe.step_fixed(frames[i], cmds[i], acts[i], out=obs, loc_out=loc)
-        elif fused:
-            # launch 1: ingest bands + fovea of the untouched ring slots; launch 2: fovea of the written slot
-            pipe.step_fixed(frames[i], cmds[i], acts[i], out=obs, loc_out=loc, mid_event=None if e is None else e[1])
+        state["ingest"](state["frames"][i], cmds[i])
+        if e is not None:
+            e[1].record()
+        if packed_mode:
+            pipe.fovea_packed(acts[i], action_type=types[i], packed=packed_buf, offsets=offsets, loc_out=loc, res_out=res_out)
+        elif types is None:
+            pipe.fovea(acts[i], out=out, loc_out=loc)
         else:
-            ingest(frames[i], cmds[i])
-            if e is not None:
-                e[1].record()
-            if packed_mode:
-                pipe.fovea_packed(acts[i], action_type=types[i], packed=packed_buf, offsets=offsets, loc_out=loc, res_out=res_out)
-            elif types is None:
-                pipe.fovea(acts[i], out=obs, loc_out=loc)
-            else:
-                pipe.fovea(acts[i], action_type=types[i], out=obs, loc_out=loc, res_out=res_out)
+            pipe.fovea(acts[i], action_type=types[i], out=out, loc_out=loc, res_out=res_out)
         if e is not None:
             e[2].record()
 
@@ -485,16 +514,67 @@ def main():
     use_ev = not args.no_events and rank == 0
     M = max(1, args.event_every)
     S = max(16, args.samples)
-    ev = []
-    if use_ev:
-        ev = [[torch.cuda.Event(enable_timing=True) for _ in range(4 if kernel_events else 3)] for _ in range(S)]
-        for e in ev:                   # create the HIP event handles (the fused call records e[1] through the C ABI)
+
+    def sample(S_, k0):
+        """S_ sampled launch pairs (every M-th step of S_ * M steps that continue the loop at step k0): mean (ingest, fovea) seconds"""
+        ev_ = [[torch.cuda.Event(enable_timing=True) for _ in range(4 if kernel_events else 3)] for _ in range(S_)]
+        for e in ev_:                  # create the HIP event handles
             for x in e:
                 x.record()
         torch.cuda.synchronize(dev)
-        for j in range(S * M):
-            step(K + j, ev[j // M] if j % M == M - 1 else None)
+        for j in range(S_ * M):
+            step(k0 + j, ev_[j // M] if j % M == M - 1 else None)
         torch.cuda.synchronize(dev)
+        t_i = sum(e[0].elapsed_time(e[1]) for e in ev_) / len(ev_) * 1e-3
+        t_f = sum((e[2].elapsed_time(e[3]) if kernel_events else e[1].elapsed_time(e[2])) for e in ev_) / len(ev_) * 1e-3
+        return t_i, t_f
+
+    ev = []
+    t_ing = t_fov = None
+    extra = {}
+    if use_ev:
+        t_ing, t_fov = sample(S, K)
+        ev = [None] * S
+        # (a) the fovea kernel against HBM: its output rotates through P buffers that together exceed the 256 MB Infinity Cache
+        #     (tools/storebench `sizes`, profiles/r04_storebench_sizes.txt: the bare 115.6 MB store stream takes 17.1 us while
+        #     the buffers it cycles through fit the cache - one or two of them - and 20.2 us from 3 buffers up)
+        P = int(args.obs_pool)
+        if P > 1 and not packed_mode and world == 1:
+            state["obs"] = [obs] + [torch.empty_like(obs) for _ in range(P - 1)]
+            for k in range(2 * P):
+                step(k)
+            ti_p, tf_p = sample(16, K + S * M)
+            extra["obs_pool"] = (P, ti_p, tf_p)
+            state["obs"] = [obs]
+        # (b) the same step on compact input screens (what the host runner stages and agx_ingest_compact reads)
+        if not use_compact and world == 1:
+            state["frames"], state["ingest"] = compact_pool(), ingest_compact
+            for k in range(40):
+                step(k)
+            torch.cuda.synchronize(dev)
+            Kc = max(K, 100)
+            tc0 = time.perf_counter()
+            for k in range(Kc):
+                step(k)
+            torch.cuda.synchronize(dev)
+            tc = (time.perf_counter() - tc0) / Kc
+            ti_c, tf_c = sample(16, Kc)
+            extra["compact"] = (tc, ti_c, tf_c, Kc)
+            state["frames"], state["ingest"] = frames, ingest
+
+    # the PCIe- and emulator-inclusive leg runs on EVERY rank at the same time (eight ranks share one host's cores, memory
+    # system and PCIe root complexes: that is what it is there to show); rank 0 prints them all
+    e2e_mine = None
+    if not args.no_e2e:
+        barrier(dist, local_rank)
+        try:
+            e2e_mine = run_e2e(dev, n, host_cores())
+        except Exception as ex:  # noqa: BLE001 - a reported extra, never the metric
+            e2e_mine = {"error": repr(ex)}
+    e2e_all = [e2e_mine]
+    if dist is not None and dist.is_initialized() and world > 1 and not args.no_e2e:
+        e2e_all = [None] * world
+        dist.all_gather_object(e2e_all, e2e_mine)
 
     out = None
     if rank == 0:
@@ -503,8 +583,6 @@ def main():
         kernels = {}
         roof = None
         if use_ev:
-            t_ing = sum(e[0].elapsed_time(e[1]) for e in ev) / len(ev) * 1e-3
-            t_fov = sum((e[2].elapsed_time(e[3]) if kernel_events else e[1].elapsed_time(e[2])) for e in ev) / len(ev) * 1e-3
             b_ing, b_fov = pipe.algorithmic_bytes("ingest_gray_raw" if gray else "ingest"), pipe.algorithmic_bytes("fovea")
             if args.kind == "flexible":
                 # 4*rh*rw (u8 windows of the 4 stacked frames) + 112,896 B per env, with rh*rw the mean over
@@ -514,12 +592,7 @@ def main():
                 b_fov = int(n * pipe.frame_stack * (win_mean + 84 * 84 * 4))
                 if packed_mode:      # ragged raw crops: rh*rw u8 read + rh*rw f32 written per stacked frame
                     b_fov = int(n * pipe.frame_stack * win_mean * 5)
-            if fused:
-                fs = pipe.frame_stack
-                plan = (("k_step_fixed (ingest + fovea of the %d untouched ring slots)" % (fs - 1), b_ing + b_fov * (fs - 1) // fs, t_ing),
-                        ("k_fovea_fixed (written slot)", b_fov // fs, t_fov))
-            else:
-                plan = (("k_ingest_grayraw" if gray else "k_ingest", b_ing, t_ing), ("k_fovea_" + args.kind, b_fov, t_fov))
+            plan = (("k_ingest_grayraw" if gray else "k_ingest", b_ing, t_ing), ("k_fovea_" + args.kind, b_fov, t_fov))
             for name, b, t in plan:
                 kernels[name] = {"avg_us": t * 1e6, "algorithmic_bytes": b, "achieved_GBps": b / t / 1e9,
                                  "frac": b / t / 1e9 / HBM_PEAK_GBS}
@@ -544,27 +617,41 @@ def main():
             "preroll": args.preroll, "events_in_timed_region": events_in_timed_region,
             "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "u8 ingest / f32 resize", "data": "synthetic",
-            "config": {"workload": f"{n}x AtariFixedFovealEnv-shaped envs per GPU (kind={args.kind}), 84x84 obs, 30x30 fov, "
-                                   "frame_stack=4, action_repeat=4, " + ("ragged raw crops packed (agx_fovea_flexible_packed)" if packed_mode else "resize_to_full")
-                                   + (f", antialias={args.antialias}" if args.kind != "fixed" else "") + ", absolute sensory actions; "
-                                   + ("device-resident synthetic RGB frames (BASELINE.json configs[1])" if not gray else
-                                      "device-resident synthetic GRAY screens (getScreenGrayscale format) - NOT the metric's workload"),
+            "config": {"workload": workload_name(args, n, packed_mode, gray, use_compact),
                        "envs_per_gpu": n, "total_envs": total_envs, "input_pool": args.pool,
-                       "step_form": ("agx_step_fixed split step (env-range parts on internal streams, AGX_STEP_SPLIT=%s); every %dth "
-                                     "step of the sampling pass as two stand-alone full-batch launches carrying the roofline's HIP events"
-                                     % (os.environ.get("AGX_STEP_SPLIT", "default 2"), M)) if split else "two stand-alone launches per step",
+                       "input_layout": ("compact screens u8 [N,2,%d,160,%s]: the rows K1 reads, as the host runner stages them (agx_ingest_compact)"
+                                        % (int(src_rows.numel()), "1" if gray else "3")) if use_compact else
+                                       "whole screens u8 [N,2,210,160,%s]" % ("1" if gray else "3"),
+                       "step_form": "two stand-alone launches per step",
                        "parallelism": f"env-shard x{world}, no collective"},
             "roofline": roof, "kernels": kernels, "build": _build_info(),
             "per_gpu": [n * K / t_ for t_ in per_rank], "per_gpu_unit": "env steps/s of each rank over its own timed region",
             "control_plane": (dist.get_backend() if dist is not None and dist.is_initialized() else "none"),
         }
+        if use_ev and "obs_pool" in extra:
+            P, ti_p, tf_p = extra["obs_pool"]
+            name = "k_fovea_" + args.kind
+            out["kernels_obs_pool"] = {
+                "buffers": P, "bytes": P * int(obs.numel()) * 4,
+                name: {"avg_us": tf_p * 1e6, "frac": kernels[name]["algorithmic_bytes"] / tf_p / 1e9 / HBM_PEAK_GBS},
+                "k_ingest": {"avg_us": ti_p * 1e6},
+                "note": "the fovea kernel's output rotating through buffers that exceed the 256 MB Infinity Cache: its rate against "
+                        "HBM; `kernels` is the product's form (two observation buffers, 231 MB, cache-resident)"}
+        if use_ev and "compact" in extra:
+            tc, ti_c, tf_c, Kc = extra["compact"]
+            out["compact_input"] = {
+                "value": n / tc, "unit": "env steps/s", "ms_per_step": tc * 1e3, "steps": Kc,
+                "k_ingest_avg_us": ti_c * 1e6, "k_ingest_frac": kernels["k_ingest_grayraw" if gray else "k_ingest"]["algorithmic_bytes"] / ti_c / 1e9 / HBM_PEAK_GBS,
+                "k_fovea_avg_us": tf_c * 1e6,
+                "note": "the same step with the screens in the host runner's compact staging layout (only the %d of 210 rows K1 "
+                        "reads, agx_ingest_compact): same results, same algorithmic bytes; never `value`" % int(src_rows.numel())}
         if world > 1:
             out["config"]["games"] = "one synthetic frame source per GPU (the game mix only changes the emulator, never the shapes)"
-        if world == 1 and not args.no_e2e:
-            try:
-                out["e2e"] = run_e2e(dev, n, host_cores())
-            except Exception as ex:  # noqa: BLE001 - a reported extra, never the metric
-                out["e2e"] = {"error": repr(ex)}
+        if not args.no_e2e:
+            if world == 1:
+                out["e2e"] = e2e_all[0]
+            else:
+                out["e2e_per_rank"] = e2e_all
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args.cpu_seconds, 1234)
         print(json.dumps(out), flush=True)

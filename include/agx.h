@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define AGX_ABI_VERSION 1
+#define AGX_ABI_VERSION 2
 
 #if defined(__GNUC__)
 #define AGX_API __attribute__((visibility("default")))
@@ -114,6 +114,11 @@ AGX_API int agx_abi_version(void);
  * and bench.py refuses a PMC traffic figure collected on a different build. */
 AGX_API const char *agx_build_info(void);
 
+/* PCI address of a HIP device ("0000:72:00.0", NUL-terminated; len >= 13): what a host runner needs to find the NUMA node
+ * the GPU hangs off (/sys/bus/pci/devices/<address>/numa_node, local_cpulist) and place its emulator threads and pinned
+ * staging there (active_gym/hostplan.py; SURVEY.md 8e "host cores partitioned NUMA-locally"). */
+AGX_API int agx_device_pci_bus_id(int device, char *buf, int len);
+
 /* Validates the configuration (mirrors `assert fov_size < obs_size`,
  * fov_env.py:112), allocates ring / head / fov_loc / fov_res on the device,
  * builds the resize tables.  The ring starts zero-filled, fov_loc = rint(init_loc),
@@ -149,6 +154,17 @@ AGX_API int agx_ingest(agx_ctx *ctx, const uint8_t *d_frames, const uint8_t *d_c
  * `ale.getScreenGrayscale()` returns them - what the reference itself reads (atari_env.py:74).  No luminance
  * arithmetic on the device (ALE's palette table has done it) and a third of the bytes over PCIe and HBM. */
 AGX_API int agx_ingest_gray_raw(agx_ctx *ctx, const uint8_t *d_gray, const uint8_t *d_cmd, void *stream);
+
+/* ---- compact source screens ---------------------------------------------------------------------------------
+ * cv2.resize(.., INTER_LINEAR) from raw_h to obs_h rows reads only some source rows (168 of 210 for 84 rows: the y0 / y1 of
+ * its table, atari_env.py:74); SURVEY.md 8d's algorithmic bytes count only those.  A host runner that stages only those rows
+ * cuts the PCIe bytes of a step by the same 20 %.
+ * agx_source_rows: rows i32 [raw_h] out (the first *n are valid, ascending; rows may be NULL to ask for n only).
+ * agx_ingest_compact / agx_ingest_gray_raw_compact: agx_ingest / agx_ingest_gray_raw (same results, bit for bit) from
+ *   d_rows u8 [N][2][n][raw_w][3]  (gray: [N][2][n][raw_w]) - row k of a compact screen = source row rows[k]. */
+AGX_API int agx_source_rows(const agx_ctx *ctx, int32_t *rows, int32_t *n);
+AGX_API int agx_ingest_compact(agx_ctx *ctx, const uint8_t *d_rows, const uint8_t *d_cmd, void *stream);
+AGX_API int agx_ingest_gray_raw_compact(agx_ctx *ctx, const uint8_t *d_rows, const uint8_t *d_cmd, void *stream);
 
 /* Same append, but from frames that are already obs-sized gray u8
  * [N][2][obs_h][obs_w] (sources that render at obs_size, e.g. the DMC path
@@ -198,11 +214,11 @@ AGX_API int agx_set_fov_state(agx_ctx *ctx, const int32_t *d_fov_loc, const int3
 AGX_API int agx_fovea_fixed(agx_ctx *ctx, const void *d_action, int action_dtype, const uint8_t *d_mask,
                     float *d_obs, int32_t *d_fov_loc, void *stream);
 
-/* ---- fused step: agx_ingest followed by agx_fovea_fixed (d_mask = NULL), same results ----------
- * One whole `FixedFovealEnv.step` image path (fov_env.py:209-221 over atari_env.py:119-148) for all envs.
- * With AGX_STEP_FUSED=1 in the environment (resize_to_full contexts) the fovea work of the ring slots this
- * step's ingest does not touch rides in the ingest launch (heterogeneous workgroups) and the written slot
- * follows in a second small launch; by default it issues the two stand-alone launches (measured equal).
+/* ---- one call for the whole step: agx_ingest followed by agx_fovea_fixed (d_mask = NULL), same results --------
+ * One whole `FixedFovealEnv.step` image path (fov_env.py:209-221 over atari_env.py:119-148) for all envs: the two
+ * stand-alone launches, in one ABI call.  (Other forms of this call - a heterogeneous fused launch, env-range parts on
+ * internal streams, one workgroup per env - were built, measured equal or slower and live in the experiments build
+ * libagx_exp.so only; this library has no knob for them.)
  * mid_event: optional hipEvent_t (may be NULL) recorded on `stream` between the two launches (profiling). */
 AGX_API int agx_step_fixed(agx_ctx *ctx, const uint8_t *d_frames, const uint8_t *d_cmd, const void *d_action,
                            int action_dtype, float *d_obs, int32_t *d_fov_loc, void *mid_event, void *stream);

@@ -52,8 +52,26 @@ typedef struct agxr_config {
     const char *rom_path;      /* ROM file ("ale_c") */
     int32_t gray_frames;       /* 0: RGB screens u8[N][2][210][160][3] (agx_ingest); 1: ALE grayscale screens
                                   u8[N][2][210][160] (getScreenGrayscale, what the reference reads; agx_ingest_gray_raw) */
+    /* Compact staging: stage only the n_src_rows screen rows listed in src_rows (ascending; agx_source_rows() of the
+     * observation context gives them: the rows cv2.resize reads, 168 of 210 for 84 x 84).  Every screen in `frames` then has
+     * n_src_rows rows instead of 210 - u8 [N][2][n_src_rows][160][3] - for agx_ingest_compact; reset screens likewise.
+     * n_src_rows = 0: whole screens.  The list is copied at agxr_create. */
+    int32_t n_src_rows;
+    const int32_t *src_rows;
+    /* Worker placement: worker w is pinned to CPU cpu_list[w % n_cpus] (pthread_setaffinity_np); n_cpus = 0: not pinned.
+     * The caller derives the list from the topology (active_gym/hostplan.py: the CPUs of the NUMA node the rank's GPU hangs
+     * off, split between the ranks that share the node).  The list is copied at agxr_create. */
+    const int32_t *cpu_list;
+    int32_t n_cpus;
     int32_t reserved;
 } agxr_config;
+
+/* Worker threads agxr_create starts when num_threads = 0: the CPUs this process may use (scheduler affinity and the
+ * cgroup CPU quota) divided by LOCAL_WORLD_SIZE (one process per GPU; 1 when unset), at least 1, at most 64. */
+AGXR_API int agxr_default_threads(void);
+/* What that figure is made of: out[0] = CPUs in the affinity mask, out[1] = cgroup quota in CPUs (0 = none),
+ * out[2] = LOCAL_WORLD_SIZE (1 when unset). */
+AGXR_API void agxr_host_cpus(int32_t out[3]);
 
 AGXR_API int agxr_create(const agxr_config *cfg, agxr_runner **out);
 AGXR_API int agxr_destroy(agxr_runner *r);
@@ -63,7 +81,8 @@ AGXR_API void agxr_set_training(agxr_runner *r, int training);   /* AtariEnv.tra
 
 /* One AtariEnv._step per env (atari_env.py:119-148).
  *   motor   i32[N]  index into the minimal action set
- *   frames  u8 [N][2][210][160][3] (or [N][2][210][160] with gray_frames)  the screens after t==2 / t==3 go to slots 0 / 1
+ *   frames  u8 [N][2][210][160][3] (or [N][2][210][160] with gray_frames; n_src_rows rows instead of 210 with compact
+ *           staging)  the screens after t==2 / t==3 go to slots 0 / 1
  *   cmd     u8 [N]  nvalid for agx_ingest
  *   reward  f64[N]  sign(raw) if clip_reward else raw;  raw f64[N];  done u8[N] (incl. life-loss terminals) */
 AGXR_API int agxr_step(agxr_runner *r, const int32_t *motor, uint8_t *frames, uint8_t *cmd, double *reward,
@@ -88,6 +107,10 @@ AGXR_API int agxr_reset(agxr_runner *r, const int32_t *idx, int32_t k, const int
  * vector step uploads the k reset screens as one contiguous copy; cmd stays indexed by env). */
 AGXR_API int agxr_reset_packed(agxr_runner *r, const int32_t *idx, int32_t k, const int32_t *noops, uint8_t *frames,
                                int64_t row_stride, uint8_t *cmd);
+
+/* Number of worker threads, and the CPU worker w is pinned to (-1: not pinned, or w out of range). */
+AGXR_API int agxr_num_threads(const agxr_runner *r);
+AGXR_API int agxr_worker_cpu(const agxr_runner *r, int32_t w);
 
 /* lives i32[N], life_termination u8[N] (either may be NULL) */
 AGXR_API int agxr_get_state(const agxr_runner *r, int32_t *lives, uint8_t *life_termination);

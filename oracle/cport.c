@@ -3,8 +3,10 @@
  *
  *   agxo_get_state   AtariEnv._get_state integer part   reference atari_env.py:73-75
  *                    ALE luminance round(.2989r+.5870g+.1140b) + OpenCV 8-bit INTER_LINEAR (11-bit fixed point)
- *   agxo_step_fixed  AtariEnv._step image part + FixedFovealEnv._fov_step (absolute, resize_to_full)
- *                    reference atari_env.py:121-133,143  fov_env.py:166-183,193-195
+ *   agxo_ingest      AtariEnv._step / _reset image part (max over the sampled screens, _reset_buffer, deque.append)
+ *                    reference atari_env.py:80-82,111-112,121-133,143
+ *   agxo_fovea_fixed FixedFovealEnv._fov_step + _get_fov_state (absolute, resize_to_full)   reference fov_env.py:166-183,193-195
+ *   agxo_step_fixed  the two in a row: one env step of the headline config
  * Arithmetic follows oracle/oracle.py function for function; tests/test_oracle_cport.py checks they agree.
  */
 #include <math.h>
@@ -43,7 +45,7 @@ static void cv_axis(int src, int dst, int is_x, cvtap *t) {
 
 /* rgb u8[210][160][3] -> out u8[oh][ow]; dsize = (ow, oh) */
 void agxo_get_state(const uint8_t *rgb, int oh, int ow, uint8_t *out) {
-    static uint8_t gray[RAW_H * RAW_W];
+    uint8_t *gray = (uint8_t *)malloc(RAW_H * RAW_W);      /* (per call: callers may step envs from several threads) */
     cvtap *tx = (cvtap *)malloc(sizeof(cvtap) * ow), *ty = (cvtap *)malloc(sizeof(cvtap) * oh);
     int *h0 = (int *)malloc(sizeof(int) * ow), *h1 = (int *)malloc(sizeof(int) * ow);
     cv_axis(RAW_W, ow, 1, tx);
@@ -58,23 +60,30 @@ void agxo_get_state(const uint8_t *rgb, int oh, int ow, uint8_t *out) {
         for (int x = 0; x < ow; ++x)
             out[y * ow + x] = (uint8_t)(((((ty[y].c0 * (h0[x] >> 4)) >> 16) + ((ty[y].c1 * (h1[x] >> 4)) >> 16) + 2) >> 2));
     }
-    free(tx); free(ty); free(h0); free(h1);
+    free(tx); free(ty); free(h0); free(h1); free(gray);
 }
 
-/* One env step of the headline config on the CPU, the way the reference does it per env:
- *   frames u8[2][210][160][3], nvalid, ring u8[fs][84][84] (oldest..newest, shifted in place),
- *   action (row, col) doubles, absolute mode, fov 30x30 -> obs double[fs][84][84] (the reference computes the
- *   resize in float64), fov_loc out. */
-void agxo_step_fixed(const uint8_t *frames, int nvalid, uint8_t *ring, int fs, int oh, int ow, int fh, int fw,
-                     const double *action, double *obs, int *fov_loc) {
+/* AtariEnv._step / _reset image part for one env (reference atari_env.py:80-82,111-112,121-133): `clear` = _reset_buffer (the
+ * stack is zero-filled first), then observation = max over the first nvalid (0..2) sampled screens (zeros for 0), deque.append.
+ *   frames u8[2][210][160][3], ring u8[fs][oh][ow] (oldest..newest, shifted in place) */
+void agxo_ingest(const uint8_t *frames, int nvalid, int clear, uint8_t *ring, int fs, int oh, int ow) {
     const int px = oh * ow;
     uint8_t *a = (uint8_t *)calloc(px, 1), *b = (uint8_t *)malloc(px);
     for (int f = 0; f < nvalid && f < 2; ++f) {
         agxo_get_state(frames + (size_t)f * RAW_H * RAW_W * 3, oh, ow, b);
         for (int i = 0; i < px; ++i) if (b[i] > a[i]) a[i] = b[i];
     }
+    if (clear) memset(ring, 0, (size_t)fs * px);
     memmove(ring, ring + px, (size_t)(fs - 1) * px);       /* deque.append */
     memcpy(ring + (size_t)(fs - 1) * px, a, px);
+    free(a); free(b);
+}
+
+/* FixedFovealEnv._fov_step + _get_fov_state, absolute mode, resize_to_full (reference fov_env.py:166-183,193-195):
+ *   ring u8[fs][oh][ow], action (row, col) doubles -> obs double[fs][oh][ow] (the reference computes the resize in float64 on
+ *   float32 k/255 values), fov_loc out. */
+void agxo_fovea_fixed(const uint8_t *ring, int fs, int oh, int ow, int fh, int fw, const double *action, double *obs, int *fov_loc) {
+    const int px = oh * ow;
     /* rint(clip(action, 0, obs - fov)) */
     int loc[2];
     const int bound[2] = {oh - fh, ow - fw};
@@ -103,5 +112,11 @@ void agxo_step_fixed(const uint8_t *frames, int nvalid, uint8_t *ring, int fs, i
             }
         }
     }
-    free(a); free(b);
+}
+
+/* One env step of the headline config on the CPU, the way the reference does it per env: agxo_ingest, then agxo_fovea_fixed. */
+void agxo_step_fixed(const uint8_t *frames, int nvalid, uint8_t *ring, int fs, int oh, int ow, int fh, int fw,
+                     const double *action, double *obs, int *fov_loc) {
+    agxo_ingest(frames, nvalid, 0, ring, fs, oh, ow);
+    agxo_fovea_fixed(ring, fs, oh, ow, fh, fw, action, obs, fov_loc);
 }

@@ -19,6 +19,8 @@ def lib():
         _lib = C.CDLL(_SO)
         _lib.agxo_get_state.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p]
         _lib.agxo_step_fixed.argtypes = [C.c_void_p, C.c_int, C.c_void_p] + [C.c_int] * 5 + [C.c_void_p] * 3
+        _lib.agxo_ingest.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int]
+        _lib.agxo_fovea_fixed.argtypes = [C.c_void_p] + [C.c_int] * 5 + [C.c_void_p] * 3
     return _lib
 
 
@@ -46,4 +48,24 @@ class EnvBatch:
             L.agxo_step_fixed(frames[i].ctypes.data, 2 if nvalid is None else int(nvalid[i]), self.ring[i].ctypes.data,
                               self.fs, self.obs[0], self.obs[1], self.fov[0], self.fov[1],
                               actions[i].ctypes.data, self.out[i].ctypes.data, self.loc[i].ctypes.data)
+        return self.out, self.loc
+
+    def ingest(self, frames, cmd):
+        """The ring part of a step with agx_ingest's command bytes: nvalid | CLEAR 0x04 (zero the stack first) | SKIP 0x08."""
+        L = lib()
+        frames = np.ascontiguousarray(frames, dtype=np.uint8)
+        for i in range(self.n):
+            c = int(cmd[i])
+            if c & 0x08:
+                continue
+            L.agxo_ingest(frames[i].ctypes.data, min(c & 3, 2), 1 if c & 0x04 else 0, self.ring[i].ctypes.data, self.fs,
+                          self.obs[0], self.obs[1])
+        return self.ring
+
+    def fovea_fixed(self, actions):
+        L = lib()
+        actions = np.ascontiguousarray(actions, dtype=np.float64)
+        for i in range(self.n):
+            L.agxo_fovea_fixed(self.ring[i].ctypes.data, self.fs, self.obs[0], self.obs[1], self.fov[0], self.fov[1],
+                               actions[i].ctypes.data, self.out[i].ctypes.data, self.loc[i].ctypes.data)
         return self.out, self.loc

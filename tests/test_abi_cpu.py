@@ -24,7 +24,7 @@ def _declared():
 
 def test_header_declares_the_expected_surface():
     names = _declared()
-    assert len(names) == 23 and "agx_ingest" in names and "agx_fovea_flexible" in names
+    assert len(names) == 27 and "agx_ingest" in names and "agx_ingest_compact" in names and "agx_source_rows" in names and "agx_fovea_flexible" in names
 
 
 def test_library_exports_every_declared_symbol():
@@ -32,7 +32,7 @@ def test_library_exports_every_declared_symbol():
     handle = ctypes.CDLL(path)
     for name in _declared():
         assert hasattr(handle, name), name
-    assert handle.agx_abi_version() == 1
+    assert handle.agx_abi_version() == 2
 
 
 def test_binding_matches_header():
@@ -45,7 +45,7 @@ def test_binding_matches_header():
     spec = importlib.util.spec_from_file_location("agx_build", os.path.join(REPO, "active-gym_amd", "build.py"))
     m = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(m)
-    assert nat.build_info() == f"libagx abi 1 src {m.source_hash()}"      # the loaded .so is built from the tree's sources
+    assert nat.build_info() == f"libagx abi {nat.ABI_VERSION} src {m.source_hash()}"      # the loaded .so is built from the tree's sources
 
 
 def test_create_fails_loudly_without_gpu_or_bad_config():
@@ -72,7 +72,7 @@ def test_runner_library_exports_header_surface():
     path = m.build_runner()
     src = open(os.path.join(REPO, "include", "agx_runner.h")).read()
     names = sorted(set(re.findall(r"^AGXR_API[^;(]*?\b(agxr_\w+)\s*\(", src, flags=re.M)))
-    assert len(names) == 12
+    assert len(names) == 16
     handle = ctypes.CDLL(path)
     for name in names:
         assert hasattr(handle, name), name

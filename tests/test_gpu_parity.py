@@ -37,7 +37,7 @@ def _t(x, dev, dtype=None):
 def test_native_library_is_loaded():
     from active_gym import _native as nat
     lib = nat.lib()
-    assert lib.agx_abi_version() == 1
+    assert lib.agx_abi_version() == nat.ABI_VERSION
     maps = open("/proc/self/maps").read()
     assert "libagx.so" in maps
     # ... and it is built from the sources in this tree (a stale .so travelling to the GPU box would make every test here
@@ -131,6 +131,40 @@ def test_ingest_other_square_sizes(dev, obs):
     p.ingest(_t(frames, dev), _t(cmd, dev))
     ring.ingest(frames, cmd & 3)
     assert np.array_equal(p.stack_u8().cpu().numpy(), ring.stack_u8())
+
+
+@pytest.mark.parametrize("gray", [False, True])
+@pytest.mark.parametrize("obs", [(84, 84), (64, 64), (96, 96), (40, 40), (128, 128), (48, 48)])
+def test_ingest_compact_equals_whole_screens(dev, obs, gray):
+    """agx_ingest_compact / agx_ingest_gray_raw_compact: only the screen rows cv2.resize reads (agx_source_rows), packed - the ring
+    must equal the whole-screen path's bit for bit, for the band12 form (84: packed rows 2 dy, 2 dy + 1) and for the general
+    kernel with its packed row table (every other size; 128 reads overlapping row pairs), with random commands."""
+    N, fs = 9, 3
+    rng = np.random.default_rng(obs[0] + gray)
+    a = _pipe(num_envs=N, kind="base", obs_size=obs, frame_stack=fs)
+    b = _pipe(num_envs=N, kind="base", obs_size=obs, frame_stack=fs)
+    rows = b.source_rows()
+    ty = O.cv_tables_y(210, obs[0])
+    want_rows = np.unique(np.concatenate([np.asarray(ty[0]), np.asarray(ty[1])]))
+    assert np.array_equal(rows, want_rows), "agx_source_rows vs the oracle's cv2 row table"
+    if obs == (84, 84):
+        assert len(rows) == 168
+    for step in range(4):
+        frames = rng.integers(0, 256, (N, 2, 210, 160) + (() if gray else (3,)), dtype=np.uint8)
+        nvalid = rng.integers(0, 3, N)
+        clear = (rng.random(N) < 0.2).astype(np.uint8)
+        skip = (rng.random(N) < 0.2).astype(np.uint8) if step else np.zeros(N, np.uint8)
+        nvalid[clear == 1] = 1
+        cmd = _t((nvalid | clear * 4 | skip * 8).astype(np.uint8), dev)
+        comp = np.ascontiguousarray(frames[:, :, rows])
+        if gray:
+            a.ingest_gray_raw(_t(frames, dev), cmd)
+            b.ingest_gray_raw_compact(_t(comp, dev), cmd)
+        else:
+            a.ingest(_t(frames, dev), cmd)
+            b.ingest_compact(_t(comp, dev), cmd)
+        assert torch.equal(a.stack_u8(), b.stack_u8()), step
+    assert a.stack_u8().any()
 
 
 def test_ingest_rejects_non_square_and_bad_shapes(dev):
@@ -808,7 +842,8 @@ def test_c_abi_demo_matches_python_binding(dev, tmp_path):
             h = ((h ^ w) * 1099511628211) & 0xFFFFFFFFFFFFFFFF
         return h
 
-    assert got["abi"] == 1 and got["N"] == N and got["steps"] == steps
+    from active_gym import _native as nat
+    assert got["abi"] == nat.ABI_VERSION and got["N"] == N and got["steps"] == steps
     assert got["ring_sum"] == int(ring.astype(np.uint64).sum()) and got["ring_hash"] == fnv(ring)
     assert got["loc_sum"] == int((loc * np.arange(1, 2 * N + 1, dtype=np.uint64)).sum())
     assert got["obs_hash"] == fnv(obs.view(np.uint32)), "float observations must agree bit for bit"

@@ -205,3 +205,82 @@ def test_gray_frames_native_equals_python_runner():
             ra = np.zeros((N, 1, 210, 160), np.uint8); rb = np.zeros_like(ra)
             assert np.array_equal(py.reset(d, out=ra), nv.reset(d, out=rb)) and np.array_equal(ra, rb)
     py.close(); nv.close()
+
+
+# the screen rows cv2.resize reads for 210 -> 84 rows (agx_source_rows of an 84 x 84 context): y0 = floor(2.5 dy + 0.75), y0 + 1
+ROWS84 = np.array(sorted({int(np.floor((dy + 0.5) * 2.5 - 0.5)) + k for dy in range(84) for k in (0, 1)}), dtype=np.int32)
+
+
+@pytest.mark.parametrize("gray", [False, True])
+def test_compact_staging_is_the_listed_rows_of_whole_screens(gray):
+    """agxr_config.src_rows: the runner stages only the listed rows - bit for bit the rows of what it stages otherwise, for step
+    screens, reset screens and packed reset screens, native and Python runner alike."""
+    _build()
+    from active_gym.native_runner import NativeHostRunner
+    from active_gym.runner import AtariHostRunner
+    assert len(ROWS84) == 168 and ROWS84[0] == 0 and ROWS84[-1] == 209
+    N, n_act = 6, 4
+    common = dict(game="g", seed=31, action_repeat=4, clip_reward=False, max_episode_length=108e3, frame_format="gray" if gray else "rgb",
+                  scripted_actions=n_act, scripted_lives=2, scripted_p_life=60, scripted_p_over=20)
+    full = NativeHostRunner(_Args(**common), N, workers=2, noop_fn=lambda: 2, backend="scripted")
+    comp = NativeHostRunner(_Args(**common), N, workers=3, noop_fn=lambda: 2, backend="scripted", src_rows=ROWS84)
+    pyc = AtariHostRunner(_Args(frame_source=lambda a, i: LcgALE(31 + i, n_act, 2, 60, 20), **common), N, workers=2, noop_fn=lambda: 2,
+                          src_rows=ROWS84)
+    px = () if gray else (3,)
+    assert full.frames.shape == (N, 2, 210, 160) + px and comp.frames.shape == pyc.frames.shape == (N, 2, 168, 160) + px
+    assert np.array_equal(full.reset(), comp.reset()) and np.array_equal(full.frames[:, 0][:, ROWS84], comp.frames[:, 0])
+    pyc.reset()
+    assert np.array_equal(pyc.frames[:, 0], comp.frames[:, 0])
+    rng = np.random.default_rng(2)
+    resets = 0
+    for step in range(60):
+        m = rng.integers(0, n_act, N)
+        a, b, c = full.step(m), comp.step(m), pyc.step(m)
+        for x, y, z in zip(a, b, c):
+            assert np.array_equal(x, y) and np.array_equal(x, z), step
+        for i in range(N):
+            for s in range(int(a[2][i])):
+                assert np.array_equal(full.frames[i, s][ROWS84], comp.frames[i, s]), (step, i, s)
+                assert np.array_equal(pyc.frames[i, s], comp.frames[i, s]), (step, i, s)
+        d = np.nonzero(a[1])[0]
+        if len(d):
+            resets += len(d)
+            packed = bool(step % 2)
+            ra = np.zeros((N, 1, 210, 160) + px, np.uint8)
+            rb = np.zeros((N, 1, 168, 160) + px, np.uint8)
+            rc = np.zeros((N, 1, 168, 160) + px, np.uint8)
+            ca, cb, cc = full.reset(d, out=ra, packed=packed), comp.reset(d, out=rb, packed=packed), pyc.reset(d, out=rc, packed=packed)
+            assert np.array_equal(ca, cb) and np.array_equal(ca, cc)
+            assert np.array_equal(ra[:, 0][:, ROWS84], rb[:, 0]) and np.array_equal(rb, rc)
+    assert resets >= 4
+    for r in (full, comp, pyc):
+        r.close()
+
+
+def test_compact_rows_are_validated():
+    _build()
+    from active_gym.native_runner import NativeHostRunner
+    common = dict(game="g", seed=5, action_repeat=4, clip_reward=False, max_episode_length=108e3)
+    for bad in ([3, 2], [0, 0], [-1, 4], [5, 210]):
+        with pytest.raises(RuntimeError, match="src_rows"):
+            NativeHostRunner(_Args(**common), 2, backend="scripted", src_rows=bad)
+
+
+def test_workers_are_pinned_to_the_listed_cpus():
+    _build()
+    from active_gym.native_runner import NativeHostRunner
+    common = dict(game="g", seed=5, action_repeat=4, clip_reward=False, max_episode_length=108e3)
+    allowed = sorted(os.sched_getaffinity(0))
+    cpus = allowed[:2]
+    r = NativeHostRunner(_Args(**common), 8, workers=5, backend="scripted", cpus=cpus)
+    assert r.num_workers == 5 and r.worker_cpus == [cpus[w % len(cpus)] for w in range(5)]
+    r.reset()
+    r.step(np.zeros(8, np.int64))                       # the pinned pool still steps every env
+    r.close()
+    u = NativeHostRunner(_Args(**common), 8, workers=3, backend="scripted")
+    assert u.num_workers == 3 and u.worker_cpus == [-1, -1, -1]
+    u.close()
+    # no explicit worker count: the library's own default (usable CPUs // LOCAL_WORLD_SIZE), capped by the env count
+    d = NativeHostRunner(_Args(**common), 2, backend="scripted")
+    assert d.num_workers == min(2, d._lib.agxr_default_threads())
+    d.close()

@@ -67,7 +67,37 @@ static float timeit(F launch, int R) {
     return ms / R * 1e3f;
 }
 
-int main() {
+// `storebench sizes`: is K2's slowdown per env beyond N = 1024 (batch sweep) the 256 MB Infinity Cache (MALL) absorbing a
+// 115.6 MB stream that is rewritten in place, or something that grows with the footprint (TLB reach)?  (1) one buffer of N x 112,896 B
+// for N = 1024 ... 8192; (2) N = 1024 written into P buffers in rotation (P x 115.6 MB: the stream no longer fits the cache, the
+// launch is the same).
+static int sizes_mode() {
+    const int R = 40;
+    const char *pol[] = {"plain", "nt", "sc1"};
+    for (int N : {256, 512, 1024, 2048, 4096, 8192}) {
+        const size_t n4 = (size_t)N * 4 * 1764, bytes = n4 * 16;
+        f4 *ob; CK(hipMalloc(&ob, bytes));
+        float us0 = timeit([&](int r) { hipLaunchKernelGGL(k_frame_rand<0>, dim3(4, N), dim3(256), 0, 0, ob, (unsigned)(r * 7919 + 1)); }, R);
+        float us2 = timeit([&](int r) { hipLaunchKernelGGL(k_frame_rand<2>, dim3(4, N), dim3(256), 0, 0, ob, (unsigned)(r * 7919 + 1)); }, R);
+        printf("one buffer   N = %5d (%7.1f MB): %-5s %8.2f us -> %.2f TB/s | %-5s %8.2f us -> %.2f TB/s  (%.2f us per 1024 envs)\n", N, bytes / 1e6,
+               pol[0], us0, bytes / us0 / 1e6, pol[2], us2, bytes / us2 / 1e6, us2 * 1024 / N);
+        CK(hipFree(ob));
+    }
+    const int N = 1024;
+    const size_t n4 = (size_t)N * 4 * 1764, bytes = n4 * 16;
+    for (int P : {1, 2, 3, 4, 8, 16}) {
+        f4 *ob; CK(hipMalloc(&ob, bytes * P));
+        float us0 = timeit([&](int r) { hipLaunchKernelGGL(k_frame_rand<0>, dim3(4, N), dim3(256), 0, 0, ob + (size_t)(r % P) * n4, (unsigned)(r * 7919 + 1)); }, R);
+        float us2 = timeit([&](int r) { hipLaunchKernelGGL(k_frame_rand<2>, dim3(4, N), dim3(256), 0, 0, ob + (size_t)(r % P) * n4, (unsigned)(r * 7919 + 1)); }, R);
+        printf("rotating     N = 1024 x %2d buffers (%7.1f MB): %-5s %8.2f us -> %.2f TB/s | %-5s %8.2f us -> %.2f TB/s\n", P, bytes * P / 1e6,
+               pol[0], us0, bytes / us0 / 1e6, pol[2], us2, bytes / us2 / 1e6);
+        CK(hipFree(ob));
+    }
+    return 0;
+}
+
+int main(int argc, char **argv) {
+    if (argc > 1 && argv[1][0] == 's') return sizes_mode();
     const int N = 1024, R = 40;
     const size_t n4 = (size_t)N * 4 * 1764, bytes = n4 * 16;
     f4 *ob; CK(hipMalloc(&ob, bytes));
