@@ -168,8 +168,11 @@ def plan_for_process(device_index: int, workers: Optional[int] = None, topo: Opt
     topo = read_topology() if topo is None else topo
     lws = max(1, int(os.environ.get("LOCAL_WORLD_SIZE", "1") or 1))
     lr = int(os.environ.get("LOCAL_RANK", "0") or 0) % lws
-    # rank r drives device r of the node, except in a one-process job, which may sit on any device
-    nodes = [gpu_numa_node(device_index if lws == 1 else q) for q in range(lws)]
+    # rank r drives device r of the node, except in a one-process job, which may sit on any device (and in rehearsals that let
+    # several ranks share one device: a rank whose device ordinal does not exist is taken to sit beside this one)
+    own = gpu_numa_node(device_index)
+    nodes = [own if (lws == 1 or q == lr) else gpu_numa_node(q) for q in range(lws)]
+    nodes = [own if v is None else v for v in nodes]
     p = plan(topo, lr, lws, nodes, workers)
     if os.environ.get("AGX_NO_PIN") == "1":
         p["cpus"] = []

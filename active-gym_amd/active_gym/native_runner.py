@@ -79,7 +79,8 @@ def _find_libale_c():
 class NativeHostRunner:
     def __init__(self, args, num_envs: int, frames: Optional[np.ndarray] = None, workers: Optional[int] = None,
                  noop_fn: Optional[Callable[[], int]] = None, env_offset: int = 0, backend: str = "scripted",
-                 noop_per_env: bool = False, src_rows: Optional[Sequence[int]] = None, cpus: Optional[Sequence[int]] = None):
+                 noop_per_env: bool = False, src_rows: Optional[Sequence[int]] = None, cpus: Optional[Sequence[int]] = None,
+                 alloc_frames: bool = True):
         """``src_rows``: compact staging - only these screen rows are staged (``ObsPipeline.source_rows()``), every screen
         in ``frames`` has ``len(src_rows)`` rows.  ``cpus``: worker w is pinned to ``cpus[w % len(cpus)]``
         (``active_gym.hostplan``).  ``workers`` None / 0: usable CPUs // LOCAL_WORLD_SIZE (agxr_default_threads)."""
@@ -127,10 +128,12 @@ class NativeHostRunner:
         self.worker_cpus = [self._lib.agxr_worker_cpu(self._h, w) for w in range(self.num_workers)]
         self.rows = RAW_H if self.src_rows is None else len(self.src_rows)
         shape = (self.num_envs, 2, self.rows, RAW_W) + (() if self.gray else (3,))
-        if frames is None:
+        if frames is None and alloc_frames:
             frames = np.zeros(shape, np.uint8)
-        assert frames.shape == shape and frames.dtype == np.uint8 and frames.flags.c_contiguous
+        if frames is not None:              # (alloc_frames=False: the native step loop owns the staging, step() / reset() here are unused)
+            assert frames.shape == shape and frames.dtype == np.uint8 and frames.flags.c_contiguous
         self.frames = frames
+        self.frames_shape = shape
         self.training = True
         self._motor = np.zeros(self.num_envs, np.int32)
         self._cmd = np.zeros(self.num_envs, np.uint8)
@@ -205,16 +208,23 @@ class NativeHostRunner:
         """Reset the envs in `idx` (all by default); env i's reset screen goes to ``out[i, 0]``, or - ``packed`` - the j-th
         reset env's to ``out[j, 0]`` (the vector env uploads the reset screens of one step as ONE contiguous copy)."""
         idx = np.arange(self.num_envs, dtype=np.int32) if idx is None else np.asarray(list(idx), dtype=np.int32)
-        lt = self.life_termination
-        # no-op counts are drawn here, in env order, only for full resets - like the Python runner
-        noops = np.array([0 if lt[i] else (self._noop_rngs[i].randrange(30) if self._noop_rngs is not None else int(self.noop_fn()))
-                          for i in idx], dtype=np.int32)
+        noops = self.draw_noops(idx)
         buf = self.frames if out is None else out
         assert buf.dtype == np.uint8 and buf.flags.c_contiguous and buf.shape[0] == self.num_envs
         stride = buf.strides[0]
         fn = self._lib.agxr_reset_packed if packed else self._lib.agxr_reset
         self._check(fn(self._h, idx.ctypes.data, len(idx), noops.ctypes.data, buf.ctypes.data, stride, self._cmd.ctypes.data))
         return self._cmd.copy()
+
+    def draw_noops(self, idx) -> np.ndarray:
+        """The ``random.randrange(30)`` draws of the envs in `idx` (reference atari_env.py:96), in that order, only for full
+        resets (a life-loss reset plays one no-op and draws nothing) - like the Python runner."""
+        lt = self.life_termination
+        return np.array([0 if lt[i] else (self._noop_rngs[i].randrange(30) if self._noop_rngs is not None else int(self.noop_fn()))
+                         for i in idx], dtype=np.int32)
+
+    def last_error(self) -> str:
+        return (self._lib.agxr_last_error(self._h) or b"").decode()
 
     def render(self, i=0, size=(256, 256)):
         out = np.empty((RAW_H, RAW_W, 3), np.uint8)

@@ -41,6 +41,9 @@ class AtariVecEnv:
     ``frame_source`` ("ale" | "synthetic" | factory), ``device`` (None -> NumPy outputs on the host like
     the reference; a cuda device -> torch tensors that stay in HBM), ``antialias``, ``num_workers``."""
 
+    _loop = None             # NativeStepLoop when the native step loop drives this env (subclasses with their own source: never)
+    _want_loop = False
+
     def __init__(self, args, num_envs: int, kind: str = "fixed", env_offset: int = 0, noop_fn=None,
                  autoreset: bool = True, noop_per_env: bool = False):
         self._noop_per_env = bool(noop_per_env)
@@ -74,9 +77,13 @@ class AtariVecEnv:
         if self._was_reset:
             raise RuntimeError("rekind() after reset()")
         if kind != self.kind:
+            if self._loop is not None:
+                self._loop.close()
+                self._loop = None
             self.pipe.close()
             self.kind = kind
             self._build_pipeline()
+            self._make_loop()
             self._build_spaces()
         return self
 
@@ -193,22 +200,41 @@ class AtariVecEnv:
         # allocated while bound to them (first touch on that node), the native runner pins one worker per CPU
         from . import hostplan
         self.host_plan = hostplan.plan_for_process(self.device.index, workers=getattr(args, "num_workers", None))
-        with hostplan.bound_to(self.host_plan["cpus"] and self.host_plan["domain"]):
-            self._alloc_staging(shape, rows, px)
         src = getattr(args, "frame_source", "ale")
-        if isinstance(src, str) and src.startswith("native"):
+        native = isinstance(src, str) and src.startswith("native")
+        # The native step loop (libagx.so: agx_loop_*, include/agx_loop.h) owns staging, copy stream, launches and the autoreset:
+        # step() is then ONE C call.  Used with the native runner and device outputs (args.native_loop = False keeps the Python
+        # loop below); the chunked-H2D form and the ragged packed observations stay on the Python loop.
+        self._loop = None
+        self._want_loop = bool(native and not self._numpy_out and getattr(args, "native_loop", True)
+                               and not int(getattr(args, "h2d_chunk_envs", 0) or 0)
+                               and not (self.kind == "flexible" and not (bool(args.mask_out) or bool(args.resize_to_full))
+                                        and getattr(args, "ragged_obs", "padded") == "packed"))
+        if not self._want_loop:
+            with hostplan.bound_to(self.host_plan["cpus"] and self.host_plan["domain"]):
+                self._alloc_staging(shape, rows, px)
+        if native:
             # C++ thread-per-core runner (libagx_runner.so): "native" = built-in scripted emulator,
             # "native:ale" = real ALE through atari_py's libale_c.so
             from .native_runner import NativeHostRunner
-            self.runner = NativeHostRunner(args, self.num_envs, frames=self._h_frames.numpy(),
+            self.runner = NativeHostRunner(args, self.num_envs, frames=None if self._want_loop else self._h_frames.numpy(),
                                            workers=self.host_plan["workers"], noop_fn=noop_fn,
                                            env_offset=env_offset, backend="ale_c" if src == "native:ale" else "scripted",
                                            noop_per_env=self._noop_per_env, src_rows=self._src_rows,
-                                           cpus=self.host_plan["cpus"])
+                                           cpus=self.host_plan["cpus"], alloc_frames=not self._want_loop)
+            self._make_loop()
         else:
             self.runner = AtariHostRunner(args, self.num_envs, frames=self._h_frames.numpy(),
                                           workers=self.host_plan["workers"], noop_fn=noop_fn,
                                           env_offset=env_offset, noop_per_env=self._noop_per_env, src_rows=self._src_rows)
+
+    def _make_loop(self):
+        if getattr(self, "_want_loop", False):
+            from . import hostplan
+            from .native_loop import NativeStepLoop
+            # its pinned staging is allocated inside: bound to this rank's CPUs (first touch on the GPU's NUMA node)
+            with hostplan.bound_to(self.host_plan["cpus"] and self.host_plan["domain"]):
+                self._loop = NativeStepLoop(self.pipe, self.runner, gray=self._gray, compact=self._compact, autoreset=self.autoreset)
 
     def _alloc_staging(self, shape, rows, px):
         # Two pinned staging sets (screens, command bytes, copy-done event), used alternately: with device outputs step()
@@ -272,6 +298,9 @@ class AtariVecEnv:
 
     # ------------------------------------------------------------------ plumbing
     def close(self):
+        if getattr(self, "_loop", None) is not None:
+            self._loop.close()
+            self._loop = None
         self.runner.close()
         self.pipe.close()
 
@@ -452,6 +481,14 @@ class AtariVecEnv:
     # ------------------------------------------------------------------ API
     def reset(self, seed=None, options=None):
         """Reset every env (the reference ignores seed/options too, atari_env.py:150-152)."""
+        if self._loop is not None:
+            self._next_obs_buffer()
+            fov = self.kind != "base"
+            self._loop.reset(self._obs, self._loc if fov else None, self._res if self.kind == "flexible" else None)
+            self.cumulative_reward[:] = 0
+            self.ep_len[:] = 0
+            self._was_reset = True
+            return self._ret_obs(self._obs), self._with_masks(self._info(np.zeros(self.num_envs)), self.num_envs)
         for st in getattr(self, "_stage", []):
             st["ev"].synchronize()
         self._ev_copy.synchronize()
@@ -486,6 +523,8 @@ class AtariVecEnv:
                 stype = self._as_device_action(action["sensory_action_type"], 0).to(torch.int32)
         if isinstance(motor, torch.Tensor):
             motor = motor.detach().cpu().numpy()
+        if self._loop is not None:
+            return self._step_native(motor, sens, stype)
         self._next_stage()                      # the other pinned set; waits only for the copy issued from it two steps ago
         self._next_dset()                       # the other device screen buffer
         self._next_obs_buffer()
@@ -552,18 +591,90 @@ class AtariVecEnv:
         self._release_dset()
         return self._ret_obs(obs), reward, done, truncated, infos
 
+    def _step_native(self, motor, sens, stype):
+        """step() through the native loop: one C call does emulators -> staging -> H2D -> ingest -> fovea -> autoreset; what is
+        left here is the bookkeeping the reference's RecordWrapper / SyncVectorEnv do in Python (counters, info dicts)."""
+        from .pipeline import _DT
+        from .runner import check_motor_actions
+        n = self.num_envs
+        fov = self.kind != "base"
+        motor = check_motor_actions(motor, self.runner.num_actions).reshape(n)
+        self._next_obs_buffer()
+        obs = self._obs
+        dt = 0
+        if sens is not None:
+            if sens.dtype not in _DT:
+                raise TypeError(f"sensory action dtype {sens.dtype} not supported (f32/f64/i32/i64)")
+            dt = _DT[sens.dtype]
+        reward, raw, done, idx, fo, fl, fr = self._loop.step(motor, sens, dt, stype, obs, self._loc if fov else None,
+                                                             self._res if self.kind == "flexible" else None)
+        self.ep_len += 1
+        self.cumulative_reward += raw                   # unclipped, fov_env.py:62
+        truncated = np.zeros(n, bool)                   # always False, atari_env.py:145
+        info = {"raw_reward": raw.copy(), "reward": self.cumulative_reward.copy(), "ep_len": self.ep_len.copy()}
+        k = len(idx)
+        final = None
+        if self.autoreset and k:
+            # terminal observations / infos of the envs that ended an episode: rows of the loop's side buffers (cloned: the loop
+            # reuses them next step), handed out as views like the Python loop's index_select rows
+            fo = fo.clone()
+            gathered = {}
+            if fl is not None:
+                gathered["fov_loc"] = fl.to(torch.int64)
+            if fr is not None:
+                gathered["fov_res"] = fr.to(torch.int64)
+            final_obs = np.empty(n, dtype=object)
+            final_info = np.empty(n, dtype=object)
+            for j, i in enumerate(idx):
+                final_obs[i] = fo[j]
+                fi = {key: (val[i].copy() if isinstance(val[i], np.ndarray) else val[i]) for key, val in info.items()}
+                for key, val in gathered.items():
+                    fi[key] = val[j]
+                final_info[i] = fi
+            final = (final_obs, final_info)
+            self.cumulative_reward[idx] = 0
+            self.ep_len[idx] = 0
+            # the returned infos carry the reset values for those envs (SyncVectorEnv overwrites them with the reset infos)
+            info["raw_reward"][idx] = 0
+            info["reward"][idx] = 0
+            info["ep_len"][idx] = 0
+        if fov:
+            # self._loc / self._res: the step's values, overwritten by the masked re-observation for the envs that were reset
+            info["fov_loc"] = self._loc.to(torch.int64)
+            if self.kind == "flexible":
+                info["fov_res"] = self._res.to(torch.int64)
+        infos = self._with_masks(self._extra_info(info), n)
+        if final is not None:
+            infos["final_observation"] = final[0]
+            infos["_final_observation"] = done.copy()
+            infos["final_info"] = final[1]
+            infos["_final_info"] = done.copy()
+        return self._ret_obs(obs), reward, done, truncated, infos
+
     def reset_envs(self, idx):
         """Reset only the envs in `idx` (what a caller without autoreset does after `done`)."""
         idx = [int(i) for i in idx]
         n = self.num_envs
+        if self._loop is not None:
+            prev = self._obs
+            self._next_obs_buffer()
+            if len(self._obs_bufs) > 1:
+                self._obs.copy_(prev)                   # the envs that are not reset keep their observation in the fresh buffer
+            fov = self.kind != "base"
+            self._loop.reset_envs(idx, self._obs, self._loc if fov else None, self._res if self.kind == "flexible" else None)
+            self.cumulative_reward[idx] = 0
+            self.ep_len[idx] = 0
+            self._was_reset = True
+            return self._ret_obs(self._obs), self._with_masks(self._info(np.zeros(n)), n)
         mask, _ = self._reset_subset(idx)
         self._ingest(self._d_rcmd)
         self.cumulative_reward[idx] = 0
         self.ep_len[idx] = 0
         # a fresh output buffer, as in reset(): the terminal observation the caller holds from step() stays untouched
+        prev = self._obs
         self._next_obs_buffer()
         if self.kind != "base" and len(self._obs_bufs) > 1:
-            self._obs.copy_(self._obs_bufs[self._obs_i ^ 1])        # masked observe: the other envs keep their observation
+            self._obs.copy_(prev)                                   # masked observe: the other envs keep their observation
         if self.kind == "base":
             obs = self._observe()
         else:

@@ -15,7 +15,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 REPO = os.path.dirname(HERE)
 SRC = os.path.join(HERE, "csrc", "agx_api.hip")
 DEPS = [SRC] + sorted(os.path.join(HERE, "csrc", f) for f in os.listdir(os.path.join(HERE, "csrc")) if f.endswith(".h")) + \
-       [os.path.join(REPO, "include", "agx.h")]
+       [os.path.join(REPO, "include", "agx.h"), os.path.join(REPO, "include", "agx_loop.h")]
 # the measured dead ends (csrc/experiments/): compiled only into libagx_exp.so, for tools/ and tests/test_gpu_variants.py
 EXP_DEPS = sorted(os.path.join(HERE, "csrc", "experiments", f) for f in os.listdir(os.path.join(HERE, "csrc", "experiments")))
 OUT_DIR = os.path.join(HERE, "lib")

@@ -349,8 +349,17 @@ const char *agx_last_error(const agx_ctx *ctx) { return ctx ? ctx->err.c_str() :
 
 int agx_device_pci_bus_id(int device, char *buf, int len) {
     if (!buf || len < 13) return fail(nullptr, AGX_E_INVALID, "agx_device_pci_bus_id: buffer of at least 13 bytes needed");
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess) {
+        (void)hipGetLastError();                 // the runtime's last-error slot is sticky: do not leave it to the caller's next HIP call
+        return fail(nullptr, AGX_E_HIP, "no HIP device");
+    }
+    if (device < 0 || device >= ndev) return fail(nullptr, AGX_E_INVALID, "device %d out of range (%d visible)", device, ndev);
     const hipError_t e = hipDeviceGetPCIBusId(buf, len, device);
-    if (e != hipSuccess) return fail(nullptr, AGX_E_HIP, "hipDeviceGetPCIBusId(%d): %s", device, hipGetErrorString(e));
+    if (e != hipSuccess) {
+        (void)hipGetLastError();
+        return fail(nullptr, AGX_E_HIP, "hipDeviceGetPCIBusId(%d): %s", device, hipGetErrorString(e));
+    }
     return AGX_OK;
 }
 
@@ -519,6 +528,9 @@ int agx_create(const agx_config *cfg, agx_ctx **out) {
         if ((rc = upload(ctx, &ctx->in_xtab12, xt12)) != AGX_OK) return bail(rc);
         if ((rc = upload(ctx, &ctx->in_ytab12, yt12)) != AGX_OK) return bail(rc);
         ctx->band12_ok = adjacent && ctx->y_affine && c.obs_h % 12 == 0 && (c.obs_w / 4) * 12 <= kThreads;
+        // phase 2 of the band12 form reads 8 bytes at byte (2 x0) & ~3 of a 320-byte gray row: never past the row + the slack above
+        for (int i = 0; i < c.obs_w && ctx->band12_ok; ++i)
+            if (((2 * x0[i]) & ~3) + 8 > 2 * kRawW + 8) ctx->band12_ok = false;
         ctx->compact12_ok = ctx->band12_ok && pairs;
         // ingest workgroup: T threads produce band_rows output rows (band_rows * ow/4 <= T and the
         // 2 * band_rows row jobs fit the T/40 loader groups x 4 iterations).  128-thread workgroups give
@@ -734,7 +746,10 @@ static IngestParams ingest_params(agx_ctx *ctx, const uint8_t *d_frames, const u
 static size_t ingest_lds(const agx_ctx *ctx) {
     return sizeof(int4) * ctx->band_rows + sizeof(int2) * ctx->cfg.obs_w + (size_t)2 * ctx->band_rows * 2 * kRawW;
 }
-static size_t band12_lds(const agx_ctx *ctx) { return sizeof(int2) * (kB12Rows + ctx->cfg.obs_w) + kB12GrayB; }
+// + 8 bytes of slack: phase 2 reads the two ALIGNED dwords around every tap pair, and for the last pair of a row (x0 = 158 at
+// 160 -> 84) the second dword lies past the row's 320 bytes - past the allocation for the very last row (its value is shifted
+// out, but the read must stay inside the workgroup's LDS)
+static size_t band12_lds(const agx_ctx *ctx) { return sizeof(int2) * (kB12Rows + ctx->cfg.obs_w) + kB12GrayB + 8; }
 
 int agx_ingest(agx_ctx *ctx, const uint8_t *d_frames, const uint8_t *d_cmd, void *stream) {
     if (!ctx) return AGX_E_INVALID;
@@ -1414,3 +1429,5 @@ int agx_fovea_flexible_packed(agx_ctx *ctx, const void *d_action, int action_dty
 }
 
 }  // extern "C"
+
+#include "agx_loop_impl.h"

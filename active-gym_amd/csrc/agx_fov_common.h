@@ -87,6 +87,14 @@ __device__ __forceinline__ LocIn load_loc_inputs(const FovParams &p, int n) {
     in.w[3] = wide ? a1.y : 0u;
     return in;
 }
+// CONTRACT of the scalar forms below: (1) everything they read - fov_loc, fov_res, the ring head, the action, the action type - was
+// written by an EARLIER launch (or the host): the scalar cache is only made coherent at a kernel boundary, so a kernel form that
+// produces loc / head in the same launch that consumes them (the experiments' single-launch steps) must use load_loc_inputs (vector
+// loads) instead; every shipped launch qualifies because the state is double-buffered and the head comes from the ingest launch
+// before.  (2) every scalar element is a naturally aligned 4-byte type: s_load ignores the two low address bits.
+static_assert(sizeof(int32_t) == 4 && sizeof(((FovParams *)nullptr)->action_type[0]) == 4 && sizeof(((FovParams *)nullptr)->head[0]) == 4 &&
+              sizeof(((FovParams *)nullptr)->loc_in[0]) == 4 && sizeof(((FovParams *)nullptr)->res_in[0]) == 4,
+              "s_load_dword reads aligned dwords: the scalar state loads need 4-byte elements");
 // The same inputs + the ring head through the SCALAR cache (the env index is workgroup-uniform): four s_loads, one wait.  A
 // scalar round trip is shorter than a vector one, and this hop sits in front of every workgroup's window fetch (K2: removing it
 // altogether was worth 1.9 us of 20.5, profiles/r03_k2_ablation.txt).  `head` may be null (returns 0).

@@ -56,6 +56,32 @@ __device__ __forceinline__ void flex3_hdwn(const unsigned char *src, float *dst,
     }
 }
 
+// The same four columns at a time: x = 4 (xl + 8 k) ... + 3.  The T window bytes of a column quad come as ONE pair of aligned
+// dwords per tap row (ds_read2_b32) + v_alignbyte_b32 (the window starts at byte c of the image row: any alignment) and four
+// v_cvt_f32_ubyteN, and the four results leave as one ds_write_b128 - a quarter of the LDS instructions of the byte form.
+// Columns up to 4 * ceil(cols / 4) are produced (the W pass reads only finite values either way: bytes are finite).
+template <int T>
+__device__ __forceinline__ void flex3_hdwn4(const unsigned char *img, int c, int row0, int yf_dp, float *R1, const float (&hw)[8],
+                                            int pitch, int xl, int cols) {
+    struct __attribute__((packed, aligned(4))) U2 { uint32_t x, y; };
+    const int quads = (cols + 3) >> 2;
+    const uint32_t sh = (uint32_t)(c & 3);
+    for (int g = xl; g < quads; g += 8) {
+        const unsigned char *s = img + row0 * pitch + ((c + 4 * g) & ~3);
+        float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+#pragma unroll
+        for (int q = 0; q < T; ++q) {
+            const U2 d = *reinterpret_cast<const U2 *>(s + q * pitch);
+            const uint32_t v = __builtin_amdgcn_alignbyte(d.y, d.x, sh);
+            a0 = fmaf(hw[q], (float)(v & 0xFFu), a0);
+            a1 = fmaf(hw[q], (float)((v >> 8) & 0xFFu), a1);
+            a2 = fmaf(hw[q], (float)((v >> 16) & 0xFFu), a2);
+            a3 = fmaf(hw[q], (float)(v >> 24), a3);
+        }
+        *reinterpret_cast<float4 *>(R1 + yf_dp + 4 * g) = make_float4(a0, a1, a2, a3);
+    }
+}
+
 // E[y][xcol] = sum_t w[t] * D[y][lo + t], y = yb + rstep * k
 template <int T>
 __device__ __forceinline__ void flex3_wcomp(const float *src, float *dst, const float (&w)[16], int dp, int ow, int rstep,
@@ -73,8 +99,17 @@ __device__ __forceinline__ void flex3_wcomp(const float *src, float *dst, const 
     }
 }
 
+// Round 4's two K4 probes, kept as compile-time switches (profiles/r04_k4_ab.txt; same box, N = 1024, shipped form 20.6-20.9 us):
+// -DAGX_K4_WAVES8 (amdgpu_waves_per_eu(8, 8): 76 -> 57 VGPRs, no spill) 21.5-22.1 us; -DAGX_K4_HDWN_QUADS (flex3_hdwn4: 200 -> 124
+// static LDS instructions, 82 VGPRs) 21.8-22.1 us; both 21.35-21.5 us.  All slower: the LDS (21.5 KB -> 7 workgroups per CU) caps the
+// occupancy either way, and the byte-wise squeeze pass is not what the launch waits for - it is store-bound like K2.
+#ifdef AGX_K4_WAVES8
+#define AGX_K4_OCC __attribute__((amdgpu_waves_per_eu(8, 8)))
+#else
+#define AGX_K4_OCC
+#endif
 template <class G>
-__global__ __launch_bounds__(kThreads) void k_fovea_flexible3(G g, Flex3Params t, FovParams p) {
+__global__ __launch_bounds__(kThreads) AGX_K4_OCC void k_fovea_flexible3(G g, Flex3Params t, FovParams p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int sl = blockIdx.x, n = blockIdx.y, tid = threadIdx.x;
     const int oh = g.oh(), ow = g.ow(), fh = g.fh();
@@ -208,11 +243,16 @@ __global__ __launch_bounds__(kThreads) void k_fovea_flexible3(G g, Flex3Params t
     if (squeeze) {
         // ---- D = Hdwn . crop   (columns up to max(rw, Tw) so that every D element the W pass reads is finite)
         if (yf < fh) {
+#ifdef AGX_K4_HDWN_QUADS
+            if (Th <= 4) flex3_hdwn4<4>(raw, c, hlo, yf * t.dp, R1, hw, wp, xl, max(rw, Tw));
+            else flex3_hdwn4<8>(raw, c, hlo, yf * t.dp, R1, hw, wp, xl, max(rw, Tw));
+#else
             const int kmax = (max(rw, Tw) + 7) >> 3;
             const unsigned char *src = win + hlo * wp + xl;
             float *dst = R1 + yf * t.dp + xl;
             if (Th <= 4) flex3_hdwn<4>(src, dst, hw, wp, kmax);
             else flex3_hdwn<8>(src, dst, hw, wp, kmax);
+#endif
         }
         __syncthreads();
         // ---- E = D . Wcomp^T, into R0 (the raw bytes are dead)

@@ -289,7 +289,7 @@ def run_e2e(dev, n, hc):
            "overlap": "double-buffered pinned staging: the emulators of step t+1 run under the H2D copy and kernels of step t",
            "host_cores_usable": hc["usable"], "host_cores_present": hc["present"],
            "resets": "scripted life-loss / game-over events at 6 / 1 per mille per emulator frame: done envs are reset inside the "
-                     "timed steps (autoreset: packed reset screens, one H2D copy + one index_copy_ per step)"}
+                     "timed steps (autoreset: packed reset screens, one H2D copy + one scatter per step)"}
     h = torch.empty((n, 2, 210, 160, 3), dtype=torch.uint8).pin_memory()
     d = torch.empty_like(h, device=dev)
     for _ in range(2):
@@ -302,7 +302,11 @@ def run_e2e(dev, n, hc):
     out["h2d_GBps"] = h.numel() * 5 / (time.perf_counter() - t0) / 1e9
     del h, d
     act = {"motor_action": np.zeros(n, np.int64), "sensory_action": np.full((n, 2), 20.0, np.float32)}
-    for fmt, steps in (("rgb", 16), ("gray", 32)):
+    # Every repeat is a window of >= 0.35 s: the job's CPU quota is enforced per 100 ms period (CFS bandwidth control), and 2 x quota
+    # busy emulator threads run unthrottled for only half of a period - a 40 ms window (what rounds 1-3 timed) catches either
+    # the burst or the stall; three periods and more give the rate the box sustains.
+    window_s = 0.35
+    for fmt in ("rgb", "gray"):
         args = AtariEnvArgs(frame_format=fmt, game="breakout", seed=1, obs_size=(84, 84), fov_size=(30, 30), fov_init_loc=(0, 0),
                             sensory_action_mode="absolute", resize_to_full=True, frame_source="native", device=str(dev),
                             num_workers=workers, h2d_chunk_envs=0, scripted_lives=3, scripted_p_life=6, scripted_p_over=1)
@@ -311,8 +315,16 @@ def run_e2e(dev, n, hc):
         out["placement"] = {"numa_node": plan["numa_node"], "workers": env.runner.num_workers, "pinned_cpus": sorted(set(env.runner.worker_cpus)),
                             "cpus_usable": plan["usable"], "per_rank_default": plan["per_rank"],
                             "staging": "pinned buffers allocated while bound to the rank's CPUs (first touch on the GPU's NUMA node)"}
+        out["step_loop"] = "native (agx_loop_step: one C call per step, autoreset inside)" if env._loop is not None else "python (active_gym/vector.py)"
         env.reset()
-        env.step(act)
+        for _ in range(8):                       # warm-up: both staging sets, both device sets, both reset sets have been through
+            env.step(act)
+        torch.cuda.synchronize(dev)
+        t0 = time.perf_counter()
+        for _ in range(8):
+            env.step(act)
+        torch.cuda.synchronize(dev)
+        steps = max(16, int(window_s / max((time.perf_counter() - t0) / 8, 1e-4)) + 1)
         times, dones = [], 0
         for _ in range(3):
             torch.cuda.synchronize(dev)
@@ -321,13 +333,13 @@ def run_e2e(dev, n, hc):
                 dones += int(env.step(act)[2].sum())
             torch.cuda.synchronize(dev)
             times.append((time.perf_counter() - t0) / steps)
-        bytes_step = int(env._h_frames.numel())          # compact staging: only the rows K1 reads cross PCIe
-        rows_staged = int(env._h_frames.shape[2])
+        shp = env.runner.frames_shape            # compact staging: only the rows K1 reads cross PCIe
+        bytes_step, rows_staged = int(np.prod(shp)), int(shp[2])
         env.close()
-        best, med = min(times), sorted(times)[1]
-        out[fmt] = {"ms_per_step": best * 1e3, "env_steps_per_s": n / best, "env_steps_per_s_median": n / med,
+        best, med, worst = min(times), sorted(times)[1], max(times)
+        out[fmt] = {"ms_per_step": best * 1e3, "env_steps_per_s": n / best, "env_steps_per_s_median": n / med, "env_steps_per_s_min": n / worst,
                     "h2d_bytes_per_step": bytes_step, "rows_staged_per_screen": rows_staged,
-                    "pcie_GBps_effective": bytes_step / best / 1e9, "steps_timed": steps,
+                    "pcie_GBps_effective": bytes_step / best / 1e9, "steps_timed": steps, "window_s": steps * med,
                     "repeats": 3, "reset_fraction": dones / (3.0 * steps * n)}
     return out
 
@@ -549,7 +561,7 @@ def main():
         # (b) the same step on compact input screens (what the host runner stages and agx_ingest_compact reads)
         if not use_compact and world == 1:
             state["frames"], state["ingest"] = compact_pool(), ingest_compact
-            for k in range(40):
+            for k in range(200):             # (the device has idled through the sampling passes' synchronisations)
                 step(k)
             torch.cuda.synchronize(dev)
             Kc = max(K, 100)

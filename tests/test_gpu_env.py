@@ -74,6 +74,20 @@ def _oracle_env(i, args, noop_iter, kind, antialias=True):
     ("fixed", dict(resize_to_full=True, frame_format="gray")),
     ("peripheral", dict(resize_to_full=False, peripheral_res=(20, 20), frame_format="gray", frame_source="native",
                         scripted_actions=4, scripted_lives=3, scripted_p_life=50, scripted_p_over=10, h2d_chunk_envs=3)),
+    # device outputs + the native runner: the NATIVE STEP LOOP (agx_loop_step: one C call per step, autoreset inside) - every
+    # kind, RGB and gray screens, compact and whole-screen staging; and the Python loop with device outputs beside it
+    ("fixed", dict(resize_to_full=True, frame_source="native", device="cuda:0", scripted_actions=4, scripted_lives=3,
+                   scripted_p_life=50, scripted_p_over=10)),
+    ("fixed", dict(resize_to_full=True, frame_source="native", device="cuda:0", scripted_actions=4, scripted_lives=3,
+                   scripted_p_life=50, scripted_p_over=10, compact_rows=False, clip_reward=True)),
+    ("fixed", dict(resize_to_full=True, frame_source="native", device="cuda:0", scripted_actions=4, scripted_lives=3,
+                   scripted_p_life=50, scripted_p_over=10, native_loop=False)),
+    ("flexible", dict(resize_to_full=False, mask_out=True, frame_source="native", device="cuda:0", scripted_actions=4,
+                      scripted_lives=2, scripted_p_life=50, scripted_p_over=10)),
+    ("peripheral", dict(resize_to_full=False, peripheral_res=(20, 20), frame_format="gray", frame_source="native", device="cuda:0",
+                        scripted_actions=4, scripted_lives=3, scripted_p_life=50, scripted_p_over=10)),
+    ("base", dict(frame_source="native", device="cuda:0", frame_format="gray", scripted_actions=6, scripted_lives=3,
+                  scripted_p_life=50, scripted_p_over=10)),
 ])
 def test_vec_env_matches_oracle_with_autoreset(kind, extra):
     from active_gym import AtariVecEnv
@@ -83,6 +97,14 @@ def test_vec_env_matches_oracle_with_autoreset(kind, extra):
     args = _args(**kw)
     noops = _Noops(1)
     env = AtariVecEnv(args, N, kind=kind, noop_fn=lambda: int(next(noops.a)))
+    on_device = getattr(args, "device", None) is not None
+    want_loop = on_device and getattr(args, "native_loop", True) and getattr(args, "frame_source", None) == "native"
+    assert (env._loop is not None) == bool(want_loop)
+    n_act = int(getattr(args, "scripted_actions", 4))
+
+    def _np(x):
+        return x.cpu().numpy() if isinstance(x, torch.Tensor) else np.asarray(x)
+
     orcs = [_oracle_env(i, args, noops.b, kind) for i in range(N)]
     rng = np.random.default_rng(3)
 
@@ -97,6 +119,8 @@ def test_vec_env_matches_oracle_with_autoreset(kind, extra):
         return fov.step(state, a)
 
     obs, infos = env.reset()
+    assert isinstance(obs, torch.Tensor) == on_device
+    obs = _np(obs)
     want = []
     for i in range(N):                      # same env order as the runner draws its no-ops
         s, info = orcs[i][0].reset()
@@ -105,7 +129,7 @@ def test_vec_env_matches_oracle_with_autoreset(kind, extra):
     np.testing.assert_allclose(obs, np.stack(want), rtol=0, atol=TOL)
     n_done = 0
     for step in range(STEPS):
-        motor = rng.integers(0, 4, N)
+        motor = rng.integers(0, n_act, N)
         if args.__dict__.get("sensory_action_mode") == "relative":
             sens = rng.uniform(-14, 14, (N, 2))
         else:
@@ -118,6 +142,11 @@ def test_vec_env_matches_oracle_with_autoreset(kind, extra):
             act["sensory_action_type"] = types.reshape(N, 1)
         obs, rew, term, trunc, infos = env.step(act)
         assert not trunc.any()
+        obs = _np(obs)
+        if kind != "base":
+            infos["fov_loc"] = _np(infos["fov_loc"])
+            if kind == "flexible":
+                infos["fov_res"] = _np(infos["fov_res"])
         for i in range(N):
             rec, fov = orcs[i]
             s, r, d, tr, info = rec.step(int(motor[i]))
@@ -129,11 +158,13 @@ def test_vec_env_matches_oracle_with_autoreset(kind, extra):
             if d:
                 n_done += 1
                 assert infos["_final_observation"][i] and infos["_final_info"][i]
-                np.testing.assert_allclose(infos["final_observation"][i], o, rtol=0, atol=TOL)
+                np.testing.assert_allclose(_np(infos["final_observation"][i]), o, rtol=0, atol=TOL)
                 fi = infos["final_info"][i]
                 assert fi["ep_len"] == info["ep_len"] and fi["reward"] == info["reward"] and fi["raw_reward"] == info["raw_reward"]
                 if fov is not None:
-                    assert np.array_equal(fi["fov_loc"], fov.fov_loc)
+                    assert np.array_equal(_np(fi["fov_loc"]), fov.fov_loc)
+                    if kind == "flexible":
+                        assert np.array_equal(_np(fi["fov_res"]), fov.fov_res)
                 s, info = rec.reset()
                 o = fov_obs(i, s, reset=True)
             np.testing.assert_allclose(obs[i], o, rtol=0, atol=TOL, err_msg=f"step {step} env {i}")
@@ -286,9 +317,14 @@ def test_recording_buffer_keys(tmp_path):
 
 @pytest.mark.parametrize("kind,factory", [("base", "AtariBaseEnv"), ("fixed", "AtariFixedFovealEnv"), ("flex", "AtariFlexibleFovealEnv"),
                                           ("per", "AtariFixedFovealPeripheralEnv")])
-def test_record_buffers_match_reference_run(kind, factory, tmp_path):
+def test_record_buffers_match_reference_run_control_flow_pinned_resize_unpinned(kind, factory, tmp_path):
     """f2 as a parity row: the drop-in envs with record=True, through the real device path, against the record buffers the
-    REFERENCE's own env stack produced over the same scripted emulator, actions and no-op draws
+    REFERENCE's own env stack produced over the same scripted emulator, actions and no-op draws.
+    WHAT THIS PINS: the reference's control flow, buffer layout and key order, rewards / dones / infos, fov_loc / fov_res - all
+    produced by the reference's own code.  WHAT IT DOES NOT: the OpenCV resize arithmetic - make_golden.py had to supply
+    `cv2.resize` from the repo's own oracle restatement (cv2 is not in the image), so the `state` / `rgb` CRC checks below are
+    "kernel == oracle restatement" through the reference's plumbing, i.e. PARITY UNPINNED (oracle resize) for those two arrays
+    (DESIGN.md section 4's table lists the restated arithmetic).
     (tests/golden/record_atari_*.npz from tests/golden/make_golden.py::_record_atari_case: fov_env.py:34-37,51-102,152-154,
     253-256,370-373 on top of atari_env.py:73-169).  Contents, not only keys: every recorded full state (u8 numerators, CRC:
     bit-exact), every 256x256 frame (CRC), actions, cumulative / returned rewards, dones, truncated flags, infos incl.
@@ -332,13 +368,15 @@ def test_record_buffers_match_reference_run(kind, factory, tmp_path):
         rgb = np.stack(buf["rgb"])
         assert rgb.dtype == np.uint8 and rgb.shape[1:] == (256, 256, 3)
         assert np.array_equal(rgb[0][::8, ::8], g[f"{tag}_rgb_first"])
-        assert [zlib.crc32(np.ascontiguousarray(f).tobytes()) for f in rgb] == g[f"{tag}_rgb_crc"].tolist()
+        assert [zlib.crc32(np.ascontiguousarray(f).tobytes()) for f in rgb] == g[f"{tag}_rgb_crc"].tolist(), \
+            "rgb frames (parity unpinned: the golden's cv2.resize is the oracle's restatement)"
         st = np.stack(buf["state"])
         assert st.dtype == np.float64                         # the reference records its float64 full state (fov_env.py:59,74)
         u8 = np.rint(st * 255.0).astype(np.uint8)
         assert np.array_equal((u8.astype(np.float32) / np.float32(255.0)).astype(np.float64), st)
         assert np.array_equal(u8[-1], g[f"{tag}_state_last_u8"])
-        assert [zlib.crc32(np.ascontiguousarray(f).tobytes()) for f in u8] == g[f"{tag}_state_crc"].tolist()
+        assert [zlib.crc32(np.ascontiguousarray(f).tobytes()) for f in u8] == g[f"{tag}_state_crc"].tolist(), \
+            "recorded states (parity unpinned: the golden's cv2.resize is the oracle's restatement)"
         for k in ("action", "reward", "done", "truncated", "return_reward"):
             assert np.array_equal(np.array(buf[k]), g[f"{tag}_{k}"]), (tag, k, buf[k])
         for k in ("fov_loc", "fov_res", "fov_size", "peripheral_res"):
@@ -413,6 +451,15 @@ def test_bench_contract_json():
     # (the per-kernel durations behind `roofline` come from a sampling pass that follows it)
     assert d["events_in_timed_region"] == 0 and d["preroll"] >= 0
     assert r["launches_timed"] >= 16 and "sampling pass" in r["timing"]
+    # round 4: the fovea kernel against HBM (its output rotating through more buffers than the Infinity Cache holds), the same step on
+    # the runner's compact staging layout, and the e2e leg's placement / staging facts
+    assert d["kernels_obs_pool"]["buffers"] >= 3 and d["kernels_obs_pool"]["k_fovea_fixed"]["avg_us"] > 0
+    ci = d["compact_input"]
+    assert ci["value"] > 0 and ci["k_ingest_avg_us"] > 0 and "configs[1]" in d["config"]["workload"]
+    e = d["e2e"]
+    assert "error" not in e, e
+    assert e["rgb"]["rows_staged_per_screen"] == 168 and e["rgb"]["h2d_bytes_per_step"] == 64 * 2 * 168 * 160 * 3
+    assert e["placement"]["workers"] >= 1 and e["step_loop"].startswith("native")
 
 
 @pytest.mark.parametrize("kind", ["fixed", "flex", "per"])

@@ -83,7 +83,7 @@ def test_two_ranks_on_the_device_path_reproduce_the_unsharded_run(chunk):
 def test_bench_two_gpu_rehearsal_prints_one_line_with_per_gpu_values():
     env = dict(os.environ, AGX_BENCH_SHARE_GPU="1", AGX_BENCH_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0")
     r = subprocess.run([sys.executable, os.path.join(REPO, "bench.py"), "--gpus", "2", "--steps", "24", "--warmup", "4", "--envs", "256",
-                        "--no-cpu-baseline", "--no-e2e"], capture_output=True, text=True, cwd=REPO, env=env, timeout=900)
+                        "--no-cpu-baseline"], capture_output=True, text=True, cwd=REPO, env=env, timeout=900)
     assert r.returncode == 0, r.stdout + r.stderr
     lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
     assert len(lines) == 1, r.stdout
@@ -92,6 +92,15 @@ def test_bench_two_gpu_rehearsal_prints_one_line_with_per_gpu_values():
     assert len(d["per_gpu"]) == 2 and all(v > 0 for v in d["per_gpu"])
     assert d["value"] <= sum(d["per_gpu"]) * 1.0001          # whole-job rate uses the slowest rank's time
     assert "cpu_baseline" not in d and "e2e" not in d
+    # the PCIe- and emulator-inclusive leg runs on every rank at once; each rank reports its own share of the host
+    # (host cores partitioned per rank): workers sized by LOCAL_WORLD_SIZE, disjoint pinned CPUs
+    e = d["e2e_per_rank"]
+    assert len(e) == 2 and all("error" not in x for x in e), e
+    assert all(x["local_world_size"] == 2 and x["rgb"]["env_steps_per_s"] > 0 and x["gray"]["env_steps_per_s"] > 0 for x in e)
+    assert all(x["rgb"]["rows_staged_per_screen"] == 168 for x in e)
+    cpus = [set(x["placement"]["pinned_cpus"]) for x in e]
+    assert cpus[0] and cpus[1] and not (cpus[0] & cpus[1]), cpus
+    assert all(x["placement"]["workers"] == x["workers"] for x in e)
 
 
 def test_bench_single_rank_over_rccl():
