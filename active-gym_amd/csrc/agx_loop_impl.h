@@ -204,8 +204,8 @@ int agx_loop_create(agx_ctx *ctx, const agx_host_source *src, const agx_loop_con
         return lfail(nullptr, AGX_E_INVALID, "agx_loop_create: struct_size %d != %zu", cfg->struct_size, sizeof(agx_loop_config));
     if (!src->step || !src->reset_packed) return lfail(nullptr, AGX_E_INVALID, "agx_loop_create: the host source needs step and reset_packed");
     const agx_config &c = ctx->cfg;
-    if (c.kind == AGX_KIND_FLEXIBLE && c.out_mode == AGX_OUT_RAW)
-        return lfail(nullptr, AGX_E_STATE, "agx_loop: the flexible raw-crop mode (ragged observations) is stepped through agx_fovea_flexible_packed by the caller");
+    // (the flexible raw-crop mode is stepped in its PADDED form here - agx_fovea_flexible into [N][fs][obs_h][obs_w]; a caller who
+    //  wants the packed ragged crops runs agx_fovea_flexible_packed itself: active_gym/vector.py keeps that on its Python loop)
     agx_loop *l = new (std::nothrow) agx_loop;
     if (!l) return lfail(nullptr, AGX_E_NOMEM, "out of host memory");
     l->ctx = ctx;

@@ -58,6 +58,8 @@ def parse():
                     help="second sampling pass of the fovea kernel with its output rotating through this many observation "
                          "buffers (3 x 115.6 MB no longer fits the 256 MB Infinity Cache: `kernels_obs_pool` is the kernel "
                          "against HBM, `kernels` the product's double-buffered form); 0 = skip")
+    ap.add_argument("--host-wait", default="spin", choices=("spin", "yield", "auto"),
+                    help="how the host thread waits in synchronize() at the end of the timed region (hipSetDeviceFlags)")
     ap.add_argument("--compact", action="store_true",
                     help="time the step on COMPACT input screens (only the 168 of 210 rows K1 reads, agx_ingest_compact: what the "
                          "host runner stages) instead of whole screens; the default run reports it beside `value` as `compact_input`")
@@ -430,6 +432,20 @@ def main():
         local_rank %= torch.cuda.device_count()
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
+    # How the host waits in synchronize(): HIP's default on a host with more logical CPUs than contexts is to YIELD the core
+    # (hipDeviceScheduleAuto), which adds a wake-up to the end of the timed region - 1-2 us per step of the driver's 20-step,
+    # 1.1 ms region (profiles/r04_sched_ab.txt: 18.46-18.91 M yielding, 18.65-19.57 M spinning, pairwise + 1-3.5 %).  The
+    # bench spins (hipDeviceScheduleSpin: the runtime polls for completion on the submitting thread); --host-wait auto restores
+    # the runtime's default.  Nothing the GPU does changes.
+    host_wait = os.environ.get("AGX_BENCH_SCHED", args.host_wait)
+    if host_wait in ("spin", "yield"):
+        import ctypes
+        try:
+            rc = ctypes.CDLL("libamdhip64.so").hipSetDeviceFlags(1 if host_wait == "spin" else 2)
+        except OSError:
+            rc = -1
+        if rc != 0:
+            host_wait = f"auto (hipSetDeviceFlags returned {rc})"
     dist = None
     if world > 1 or os.environ.get("AGX_BENCH_FORCE_DIST") == "1":
         import torch.distributed as dist
@@ -626,7 +642,7 @@ def main():
         out = {
             "metric": "env steps/sec at N=1024 AtariFixedFovealEnv; 1/2/4/8-GPU scaling",
             "value": total_envs * K / elapsed, "unit": "env steps/s", "n_gpus": world, "steps": K, "warmup": args.warmup,
-            "preroll": args.preroll, "events_in_timed_region": events_in_timed_region,
+            "preroll": args.preroll, "events_in_timed_region": events_in_timed_region, "host_wait": host_wait,
             "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "u8 ingest / f32 resize", "data": "synthetic",
             "config": {"workload": workload_name(args, n, packed_mode, gray, use_compact),

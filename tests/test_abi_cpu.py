@@ -83,3 +83,28 @@ def test_runner_library_exports_header_surface():
     h = ctypes.c_void_p()
     assert nr.lib().agxr_create(ctypes.byref(cfg), ctypes.byref(h)) != 0 and not h.value
     assert b"struct_size" in nr.lib().agxr_last_error(None)
+
+
+def test_loop_header_surface_is_exported_and_bound():
+    """include/agx_loop.h (the native step loop inside libagx.so) <-> the library's exports <-> active_gym/native_loop.py; the
+    callback table's layout; a loop cannot be created without a context (no compute calls here)."""
+    path = _build()
+    src = open(os.path.join(REPO, "include", "agx_loop.h")).read()
+    names = sorted(set(re.findall(r"^AGX_API[^;(]*?\b(agx_loop_\w+)\s*\(", src, flags=re.M)))
+    assert names == ["agx_loop_create", "agx_loop_destroy", "agx_loop_last_error", "agx_loop_reset", "agx_loop_reset_envs", "agx_loop_step"]
+    handle = ctypes.CDLL(path)
+    for name in names:
+        assert hasattr(handle, name), name
+    from active_gym import native_loop as nl
+    assert sorted(nl.SIGNATURES) == names
+    assert ctypes.sizeof(nl.AgxHostSource) == 5 * ctypes.sizeof(ctypes.c_void_p) and ctypes.sizeof(nl.AgxLoopConfig) == 16
+    assert ctypes.sizeof(nl.AgxLoopResult) == 72
+    lib = nl._lib()
+    h = ctypes.c_void_p()
+    cfg = nl.AgxLoopConfig(ctypes.sizeof(nl.AgxLoopConfig), 0, 1, 1)
+    assert lib.agx_loop_create(None, ctypes.byref(nl.AgxHostSource()), ctypes.byref(cfg), ctypes.byref(h)) != 0 and not h.value
+    assert b"null argument" in lib.agx_loop_last_error(None)
+    # the host source's entry points are those of libagx_runner.so, with exactly the callback signatures the loop declares
+    hdr = open(os.path.join(REPO, "include", "agx_runner.h")).read()
+    assert "agxr_step(agxr_runner *r, const int32_t *motor, uint8_t *frames, uint8_t *cmd, double *reward,\n" in hdr.replace("AGXR_API int ", "")
+    assert "agxr_reset_packed(agxr_runner *r, const int32_t *idx, int32_t k, const int32_t *noops, uint8_t *frames,\n" in hdr.replace("AGXR_API int ", "")

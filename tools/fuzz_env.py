@@ -5,6 +5,7 @@ import os, sys, time, traceback
 REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path[:0] = [os.path.join(REPO, "active-gym_amd"), REPO, os.path.join(REPO, "tests")]
 import numpy as np
+import torch
 from active_gym import AtariEnvArgs, AtariVecEnv
 from lcg_ale import LcgALE
 from oracle import oracle as O
@@ -29,13 +30,21 @@ def one_case(k):
     s0 = int(rng.integers(0, 10000))
     noop_seq = rng.integers(0, 30, 4000).tolist()
     it_a, it_b = iter(noop_seq), iter(noop_seq)
+    # round 4: device outputs (the native step loop when the native runner feeds them, unless switched off), compact / whole-screen
+    # staging
+    on_device = bool(rng.integers(0, 2))
+    native_loop = bool(rng.integers(0, 4))
+    compact = bool(rng.integers(0, 4))
+    chunk = int(rng.integers(0, 3))
     cfg = dict(kind=kind, N=N, ar=ar, fs=fs, clip=clip, training=training, native=native, gray=gray, mode=mode, out=out,
-               n_act=n_act, lives=lives, p_life=p_life, p_over=p_over, seed=s0)
+               n_act=n_act, lives=lives, p_life=p_life, p_over=p_over, seed=s0, on_device=on_device, native_loop=native_loop,
+               compact=compact, chunk=chunk)
     kw = dict(fov_size=(30, 30), fov_init_loc=(3.5, 4.49), sensory_action_mode=mode, sensory_action_space=(-9.0, 11.0),
               resize_to_full=(out == "resize"), mask_out=(out == "mask"), peripheral_res=(20, 20))
     src = "native" if native else (lambda a, i: LcgALE(a.seed + i, n_act, lives, p_life, p_over))
     args = AtariEnvArgs(game="g", seed=s0, obs_size=(84, 84), frame_stack=fs, action_repeat=ar, clip_reward=clip,
-                        frame_source=src, frame_format="gray" if gray else "rgb", h2d_chunk_envs=int(rng.integers(0, 3)),
+                        frame_source=src, frame_format="gray" if gray else "rgb", h2d_chunk_envs=chunk,
+                        device="cuda:0" if on_device else None, native_loop=native_loop, compact_rows=compact,
                         scripted_actions=n_act, scripted_lives=lives, scripted_p_life=p_life, scripted_p_over=p_over, **kw)
     env = AtariVecEnv(args, N, kind=kind, noop_fn=lambda: int(next(it_a)))
     if not training:
@@ -61,7 +70,11 @@ def one_case(k):
             return fov.reset(s)
         return fov.step(s, a, np.array((t,))) if kind == "flexible" else fov.step(s, a)
 
+    def npy(x):
+        return x.cpu().numpy() if isinstance(x, torch.Tensor) else np.asarray(x)
+
     def cmp(i, got, want, what):
+        got = npy(got)
         if kind == "flexible" and out == "raw":
             rh, rw = chains[i][1].fov_res
             got = got[:, :rh, :rw]
@@ -83,6 +96,9 @@ def one_case(k):
         if kind == "flexible":
             act["sensory_action_type"] = types
         obs, rew, term, trunc, infos = env.step(act)
+        for key in ("fov_loc", "fov_res"):
+            if key in infos:
+                infos[key] = npy(infos[key])
         for i in range(N):
             rec, fov = chains[i]
             s, r, d, tr, info = rec.step(int(motor[i]))
