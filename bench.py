@@ -346,7 +346,7 @@ def run_e2e(dev, n, hc):
     return out
 
 
-def pmc_traffic(kernel, n_envs, kind):
+def pmc_traffic(kernel, n_envs, kind, compact=False):
     """HBM bytes per launch of `kernel` from the committed PMC profile (profiles/r*_traffic*.json: FETCH_SIZE and
     WRITE_SIZE collected in separate rocprofv3 --pmc passes of this same command by tools/traffic.sh, FETCH_SIZE
     x2 as MI355X_MICROARCH.md prescribes for gfx950 - the factor re-measured on 12 B/lane and 16 B/lane reads of a
@@ -364,6 +364,8 @@ def pmc_traffic(kernel, n_envs, kind):
         try:
             prof = json.load(open(f))
             e = prof["kernels"][kernel]
+            if ("--compact" in str(prof.get("bench_args", ""))) != bool(compact):
+                continue                        # a profile of the other input layout: a different K1 kernel
             if prof.get("build") != nat.build_info():
                 if why is None:                 # name the NEWEST profile that does not match, not the oldest
                     why = f"{os.path.relpath(f, REPO)} was collected on '{prof.get('build')}', this library is '{nat.build_info()}': stale, not quoted"
@@ -632,7 +634,7 @@ def main():
                                f"{M}th step of a {S * M}-step sampling pass that continues the step loop right after the timed region "
                                "(the timed region itself carries no events)" if kernel_events else
                                f"HIP events recorded on the launch stream around every {M}th step of a {S * M}-step sampling pass after the timed region")}
-            tr, why = pmc_traffic(dom, n, args.kind)
+            tr, why = pmc_traffic(dom, n, args.kind, use_compact)
             if tr is not None:
                 roof["traffic"] = tr["traffic"]
                 roof["traffic_unit"] = "bytes per launch"

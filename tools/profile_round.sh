@@ -5,7 +5,7 @@
 # same commands; part 2: PMC traffic (FETCH_SIZE / WRITE_SIZE, separate passes, calibrated) and the SQ / TCC counter
 # summaries.  Default: both.  Progress goes to the log files as it runs (a silent command is killed after 7 minutes).
 set -u
-TAG=${1:-r03}
+TAG=${1:-r04}
 PART=${2:-all}
 OUT=gpurun_out/$TAG
 mkdir -p $OUT
@@ -25,7 +25,8 @@ if [ "$PART" = all ] || [ "$PART" = 1 ]; then
   echo "== kernel trace"
   for s in fixed: $SUB; do
     name=${s%%:*}; args=$(echo ${s#*:} | tr '@' ' ')
-    timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/kt_$name -- python3 bench.py $args --no-cpu-baseline --no-e2e > $OUT/bench_under_rocprof_$name.json 2> $OUT/kt_$name.err || echo "kernel trace $name failed"
+    # --obs-pool 0: the trace's average of the fovea kernel is then the product form alone (the pool pass has its own events)
+    timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/kt_$name -- python3 bench.py $args --obs-pool 0 --no-cpu-baseline --no-e2e > $OUT/bench_under_rocprof_$name.json 2> $OUT/kt_$name.err || echo "kernel trace $name failed"
     f=$(find $OUT/kt_$name -name '*kernel_stats.csv' | head -1)
     [ -n "$f" ] && { head -1 $f; grep 'agx::' $f; } > $OUT/kernel_stats_$name.csv
   done
@@ -36,6 +37,9 @@ if [ "$PART" = all ] || [ "$PART" = 2 ]; then
     AGX_TRAFFIC_BENCH_ARGS="--kind $k" bash tools/traffic.sh $OUT/traffic_$k > $OUT/traffic_$k.log 2>&1
     cp $OUT/traffic_$k/traffic.json $OUT/traffic_$k.json 2>/dev/null
   done
+  # the same step on compact input screens (k_ingest_full12_compact): what K1 fetches when its rows are a gap-free stream
+  AGX_TRAFFIC_BENCH_ARGS="--kind fixed --compact" bash tools/traffic.sh $OUT/traffic_fixed_compact > $OUT/traffic_fixed_compact.log 2>&1
+  cp $OUT/traffic_fixed_compact/traffic.json $OUT/traffic_fixed_compact.json 2>/dev/null
   echo "== pmc"
   for k in fixed peripheral flexible; do
     AGX_PMC_BENCH_ARGS="--kind $k" bash tools/pmc.sh $OUT/pmc_$k > $OUT/pmc_$k.log 2>&1
