@@ -94,6 +94,7 @@ struct agx_ctx {
         int step_env = 0;        // AGX_STEP_ENV          agx_step_fixed as ONE launch, one workgroup per env (k_step_env)
         int split = 0;           // AGX_STEP_SPLIT        env-range parts of agx_step_fixed on internal streams
         int aux_prio = 0;        // AGX_STEP_AUX_PRIO     -1 | 0 | 1: priority of the internal streams relative to normal
+        int packed_wave = 0;     // AGX_PACKED_WAVE       packed ragged crops with one wave (64-thread workgroup) per (slot, env) item
     } tune;
     std::string err;
 };
@@ -449,6 +450,7 @@ int agx_create(const agx_config *cfg, agx_ctx **out) {
     ctx->tune.step_env = env_int("AGX_STEP_ENV");
     ctx->tune.split = env_int("AGX_STEP_SPLIT");
     ctx->tune.aux_prio = env_int("AGX_STEP_AUX_PRIO", 0);
+    ctx->tune.packed_wave = env_int("AGX_PACKED_WAVE");
 #endif
     DeviceGuard g(c.device);
     int rc = AGX_OK;
@@ -1397,6 +1399,14 @@ int agx_fovea_flexible_packed(agx_ctx *ctx, const void *d_action, int action_dty
         fr.offsets = d_offsets;
         const dim3 grid(c.frame_stack, c.num_envs), block(kThreads);
         using GS = GeomS<84, 84, 30, 30>;
+#ifdef AGX_EXPERIMENTS
+        if (ctx->tune.packed_wave != 0) {              // one wave per (slot, env) item: measured slower (docs/HISTORY.md, round 4)
+            if (c.obs_h == 84 && c.obs_w == 84 && c.fov_h == 30 && c.fov_w == 30)
+                AGX_LAUNCH(1, (k_fovea_flexible_raw3_wave<GS>), grid, dim3(64), ctx->fr_lds, S(stream), GS{}, fr, p);
+            else
+                AGX_LAUNCH(1, (k_fovea_flexible_raw3_wave<GeomR>), grid, dim3(64), ctx->fr_lds, S(stream), gr, fr, p);
+        } else
+#endif
         if (c.obs_h == 84 && c.obs_w == 84 && c.fov_h == 30 && c.fov_w == 30)
             AGX_LAUNCH(1, (k_fovea_flexible_raw3<GS, kRawPacked>), grid, block, ctx->fr_lds, S(stream), GS{}, fr, p);
         else

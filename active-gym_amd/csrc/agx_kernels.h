@@ -25,4 +25,5 @@
 #include "agx_k4_raw3.h"
 #ifdef AGX_EXPERIMENTS
 #include "experiments/agx_experiments.h"   // measured dead ends: tools/ and the variants test only, never in libagx.so
+#include "experiments/agx_packed_wave.h"
 #endif

@@ -14,7 +14,7 @@ for p in (REPO, os.path.join(REPO, "active-gym_amd"), os.path.join(REPO, "tests"
 import numpy as np
 import torch
 
-KNOBS = ("AGX_INGEST_NO_FULL", "AGX_INGEST_T", "AGX_INGEST_BAND_ROWS", "AGX_INGEST_PIPE", "AGX_INGEST_WAVE", "AGX_FOVEA_PAIR",
+KNOBS = ("AGX_PACKED_WAVE", "AGX_INGEST_NO_FULL", "AGX_INGEST_T", "AGX_INGEST_BAND_ROWS", "AGX_INGEST_PIPE", "AGX_INGEST_WAVE", "AGX_FOVEA_PAIR",
          "AGX_STEP_FUSED", "AGX_STEP_SPLIT", "AGX_STEP_AUX_PRIO", "AGX_INGEST_PAIR12", "AGX_STEP_ENV")
 VARIANTS = [{"AGX_INGEST_T": "128"}, {"AGX_INGEST_BAND_ROWS": "7"}, {"AGX_INGEST_BAND_ROWS": "11"}, {"AGX_INGEST_PIPE": "2"},
             {"AGX_INGEST_PIPE": "7"}, {"AGX_INGEST_WAVE": "1"}, {"AGX_INGEST_NO_FULL": "1"}, {"AGX_INGEST_PAIR12": "1"},
@@ -95,6 +95,36 @@ def main():
                     break
             if ok:
                 report["variants"][name] = "ok"
+            d.close()
+            v.close()
+    # the packed ragged crops with one wave per (slot, env) item (round 4, experiments/agx_packed_wave.h) against the shipped form
+    for geom in ("headline", "generic"):
+        fov = (30, 30) if geom == "headline" else (26, 34)
+        N, fs = 45, 3
+        kw = dict(num_envs=N, kind="flexible", obs_size=(84, 84), fov_size=fov, frame_stack=fs, resize_to_full=False, mask_out=False,
+                  fov_init_loc=(0, 0), sensory_action_mode="absolute", device=dev)
+        for aa in (True, False):
+            for k in KNOBS:
+                os.environ.pop(k, None)
+            d = ObsPipeline(antialias=aa, **kw)
+            os.environ["AGX_PACKED_WAVE"] = "1"
+            v = ObsPipeline(antialias=aa, **kw)
+            name = f"{geom}:flexible packed aa={int(aa)}:AGX_PACKED_WAVE=1"
+            report["variants"][name] = "ok"
+            rng = np.random.default_rng(5 + aa)
+            for step in range(6):
+                st = torch.from_numpy(rng.integers(0, 256, (N, fs, 84, 84), dtype=np.uint8)).to(dev)
+                d.set_stack_u8(st)
+                v.set_stack_u8(st)
+                types = rng.integers(0, 2, N).astype(np.int32)
+                a = np.where(types[:, None] == 1, rng.integers(1, 85, (N, 2)), rng.integers(-5, 80, (N, 2))).astype(np.int64)
+                at, tt = torch.from_numpy(a).to(dev), torch.from_numpy(types).to(dev)
+                pd, od, ld, rd = d.fovea_packed(at, action_type=tt)
+                pv, ov, lv, rv = v.fovea_packed(at, action_type=tt)
+                tot = int(od[-1])
+                if not (torch.equal(od, ov) and torch.equal(ld, lv) and torch.equal(rd, rv) and torch.equal(pd[:tot], pv[:tot])):
+                    report["variants"][name] = f"differs from the shipped packed kernel at step {step}"
+                    break
             d.close()
             v.close()
     for k in KNOBS:
