@@ -610,3 +610,69 @@ def test_vec_env_on_a_device_that_is_not_the_current_one():
         assert torch.equal(oa.cpu(), ob.cpu())
     a.close()
     b.close()
+
+
+@pytest.mark.parametrize("kind,fmt", [("fixed", "rgb"), ("flexible", "gray"), ("base", "gray")])
+def test_native_loop_equals_python_loop_at_scale(kind, fmt):
+    """The native step loop (agx_loop_step) against the Python loop of vector.py, same native runner, same seeds, at a batch large
+    enough for what the N = 5 oracle chains never reach: several hundred envs ending an episode in ONE step (the gathers and the
+    scatter run with grid.y = k in the hundreds), more done envs than a 256-env scan block, every step with resets.  Everything the
+    step returns must be identical: observations, rewards, terminals, counters, fov state, every terminal observation / info."""
+    import zlib
+    from active_gym import AtariEnvArgs, AtariVecEnv
+    N, STEPS = 700, 14
+    kw = dict(game="g", seed=11, obs_size=(84, 84), fov_size=(30, 30), fov_init_loc=(2, 3), sensory_action_mode="absolute",
+              resize_to_full=True, frame_source="native", frame_format=fmt, device="cuda:0", num_workers=4,
+              scripted_actions=4, scripted_lives=2, scripted_p_life=250, scripted_p_over=60)      # ~ half of the envs end per step
+    envs = []
+    for loop in (True, False):
+        import random
+        rnd = random.Random(5)
+        e = AtariVecEnv(AtariEnvArgs(native_loop=loop, **kw), N, kind=kind, noop_fn=lambda r=rnd: r.randrange(30))
+        assert (e._loop is not None) == loop
+        envs.append(e)
+    a, b = envs
+
+    def crc(t):
+        return zlib.crc32(t.detach().cpu().numpy().tobytes())
+
+    oa, _ = a.reset()
+    ob, _ = b.reset()
+    assert crc(oa) == crc(ob)
+    rng = np.random.default_rng(1)
+    most = 0
+    for step in range(STEPS):
+        motor = rng.integers(0, 4, N)
+        if kind == "base":
+            act = motor
+        else:
+            types = rng.integers(0, 2, N)
+            sens = np.where(types[:, None] == 1, rng.integers(8, 70, (N, 2)), rng.integers(-5, 60, (N, 2))).astype(np.int64)
+            act = {"motor_action": motor, "sensory_action": sens}
+            if kind == "flexible":
+                act["sensory_action_type"] = types
+        ra, rb = a.step(act), b.step(act)
+        assert crc(ra[0]) == crc(rb[0]), step
+        assert np.array_equal(ra[1], rb[1]) and np.array_equal(ra[2], rb[2]) and np.array_equal(ra[3], rb[3]), step
+        ia, ib = ra[4], rb[4]
+        assert set(ia) == set(ib), (step, sorted(ia), sorted(ib))
+        for key in ("raw_reward", "reward", "ep_len"):
+            assert np.array_equal(ia[key], ib[key]), (step, key)
+        for key in ("fov_loc", "fov_res"):
+            if key in ia:
+                assert torch.equal(ia[key], ib[key]), (step, key)
+        done = ra[2]
+        most = max(most, int(done.sum()))
+        if done.any():
+            assert np.array_equal(ia["_final_observation"], ib["_final_observation"])
+            for i in np.nonzero(done)[0]:
+                assert crc(ia["final_observation"][i]) == crc(ib["final_observation"][i]), (step, i)
+                fa, fb = ia["final_info"][i], ib["final_info"][i]
+                assert set(fa) == set(fb)
+                for key in fa:
+                    va, vb = fa[key], fb[key]
+                    assert (torch.equal(va, vb) if isinstance(va, torch.Tensor) else va == vb), (step, i, key)
+    assert most > 256, most
+    assert torch.equal(a.pipe.stack_u8(), b.pipe.stack_u8())
+    a.close()
+    b.close()
