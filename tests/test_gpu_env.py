@@ -676,3 +676,61 @@ def test_native_loop_equals_python_loop_at_scale(kind, fmt):
     assert torch.equal(a.pipe.stack_u8(), b.pipe.stack_u8())
     a.close()
     b.close()
+
+
+def test_c_loop_demo_matches_python_env(tmp_path):
+    """examples/c_loop_demo.cpp drives the WHOLE vector step from plain C++ - libagx_runner.so's emulators (compact staging) into
+    libagx.so's native step loop, autoreset inside, no Python, no torch; the same envs through AtariVecEnv must give the same
+    observation / terminal-observation checksums, reward sums and done counts at every step."""
+    import json
+    import os
+    import shutil
+    import subprocess
+    from active_gym import AtariEnvArgs, AtariVecEnv
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    if not os.path.exists(hipcc):
+        pytest.skip("hipcc not on this box")
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = str(tmp_path / "c_loop_demo")
+    libdir = os.path.join(repo, "active-gym_amd", "lib")
+    subprocess.run([hipcc, "--offload-arch=gfx950", "-O2", "-I", os.path.join(repo, "include"), os.path.join(repo, "examples", "c_loop_demo.cpp"),
+                    "-o", exe, "-L", libdir, "-lagx", "-lagx_runner", f"-Wl,-rpath,{libdir}"], check=True, timeout=600)
+    N, STEPS = 48, 40
+    out = subprocess.run([exe, str(N), str(STEPS)], check=True, capture_output=True, text=True, timeout=300).stdout
+    got = [json.loads(l) for l in out.splitlines() if l.startswith("{")]
+    assert len(got) == STEPS + 1
+
+    def fnv(t):
+        h = 1469598103934665603
+        for w in t.detach().cpu().contiguous().numpy().view(np.uint32).reshape(-1).tolist():
+            h = ((h ^ w) * 1099511628211) & 0xFFFFFFFFFFFFFFFF
+        return h
+
+    k = [0]
+
+    def noop():
+        v = (k[0] * 7 + 3) % 30
+        k[0] += 1
+        return v
+
+    args = AtariEnvArgs(game="g", seed=21, obs_size=(84, 84), fov_size=(30, 30), fov_init_loc=(0, 0), sensory_action_mode="absolute",
+                        resize_to_full=True, frame_source="native", device="cuda:0", num_workers=4, scripted_actions=4,
+                        scripted_lives=2, scripted_p_life=60, scripted_p_over=20)
+    env = AtariVecEnv(args, N, kind="fixed", noop_fn=noop)
+    assert env._loop is not None and env._compact
+    obs, _ = env.reset()
+    assert fnv(obs) == got[0]["obs"]
+    n_done = 0
+    for t in range(STEPS):
+        motor = np.array([(t + i) % 4 for i in range(N)])
+        sens = np.array([[(t * 5 + i * 3) % 60 - 2.5, (t * 11 + i) % 64 - 4.0] for i in range(N)], np.float32)
+        obs, rew, term, trunc, infos = env.step({"motor_action": motor, "sensory_action": sens})
+        g = got[t + 1]
+        assert g["step"] == t and g["n_done"] == int(term.sum()) and g["reward"] == float(rew.sum()), (t, g)
+        assert fnv(obs) == g["obs"], t
+        if term.any():
+            fin = torch.stack([infos["final_observation"][i] for i in np.nonzero(term)[0]])
+            assert fnv(fin) == g["final"], t
+            n_done += int(term.sum())
+    assert n_done >= 10
+    env.close()
