@@ -108,7 +108,10 @@ class NativeStepLoop:
             e, self._cb_error = self._cb_error, None
             raise e
         if rc:
-            raise nat.AgxError(rc, (self._lib.agx_loop_last_error(self._h) or b"").decode())
+            msg = (self._lib.agx_loop_last_error(self._h) or b"").decode()
+            if msg.startswith("host source"):          # the callback's own reason (e.g. a motor action outside the action set)
+                msg += ": " + self.runner.last_error()
+            raise nat.AgxError(rc, msg)
 
     def _draw_noops(self, _user, idx, k, out):
         """C callback: the no-op counts of the k envs about to be reset, drawn where the reference draws them (Python's

@@ -158,7 +158,7 @@ class NativeHostRunner:
 
     def set_frames(self, frames: np.ndarray):
         """Point the runner at another staging buffer of the same shape (double-buffered pinned staging)."""
-        assert frames.shape == self.frames.shape and frames.dtype == np.uint8 and frames.flags.c_contiguous
+        assert tuple(frames.shape) == tuple(self.frames_shape) and frames.dtype == np.uint8 and frames.flags.c_contiguous
         self.frames = frames
 
     def train(self):
@@ -181,7 +181,13 @@ class NativeHostRunner:
         self._lib.agxr_get_state(self._h, None, out.ctypes.data)
         return out.astype(bool)
 
+    def _need_frames(self):
+        if self.frames is None:
+            raise RuntimeError("this runner was created without a staging buffer (alloc_frames=False: the native step loop owns the "
+                               "staging and drives the emulators); pass out= / set_frames() to use it directly")
+
     def step(self, motor_actions):
+        self._need_frames()
         self._motor[:] = np.asarray(motor_actions).reshape(self.num_envs)
         self._check(self._lib.agxr_step(self._h, self._motor.ctypes.data, self.frames.ctypes.data, self._cmd.ctypes.data,
                                         self._rew.ctypes.data, self._raw.ctypes.data, self._done.ctypes.data))
@@ -191,6 +197,7 @@ class NativeHostRunner:
         """Start a step; returns the number of chunks.  ``step_wait(c)`` blocks until chunk c's screens are in
         ``frames`` (so their H2D copy can start while later chunks still emulate); ``step_finish()`` returns what
         :meth:`step` returns."""
+        self._need_frames()
         self._motor[:] = np.asarray(motor_actions).reshape(self.num_envs)
         chunk_envs = max(1, min(int(chunk_envs), self.num_envs))
         self._check(self._lib.agxr_step_begin(self._h, self._motor.ctypes.data, self.frames.ctypes.data, self._cmd.ctypes.data,
@@ -209,6 +216,8 @@ class NativeHostRunner:
         reset env's to ``out[j, 0]`` (the vector env uploads the reset screens of one step as ONE contiguous copy)."""
         idx = np.arange(self.num_envs, dtype=np.int32) if idx is None else np.asarray(list(idx), dtype=np.int32)
         noops = self.draw_noops(idx)
+        if out is None:
+            self._need_frames()
         buf = self.frames if out is None else out
         assert buf.dtype == np.uint8 and buf.flags.c_contiguous and buf.shape[0] == self.num_envs
         stride = buf.strides[0]

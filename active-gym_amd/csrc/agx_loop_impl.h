@@ -22,6 +22,14 @@ __global__ __launch_bounds__(kThreads) void k_row_copy(RowCopyParams p) {
     const int64_t s = p.gather ? e : j, d = p.gather ? j : e;
     p.dst[d * p.dst_pitch16 + q] = p.src[s * p.src_pitch16 + q];
 }
+// the same gather in 4-byte words, for observation rows that are not a multiple of 16 bytes (a raw-crop context with an odd
+// fov size: fs * fov_h * fov_w floats per env); grid = (ceil(row32 / 256), k)
+__global__ __launch_bounds__(kThreads) void k_row_gather32(const uint32_t *src, const int32_t *idx, uint32_t *dst, int64_t row32) {
+    const int64_t q = (int64_t)blockIdx.x * kThreads + threadIdx.x;
+    if (q >= row32) return;
+    const int j = blockIdx.y;
+    dst[(int64_t)j * row32 + q] = src[(int64_t)idx[j] * row32 + q];
+}
 // 8-byte rows (fov_loc / fov_res): dst[j] = src[idx[j]]
 __global__ __launch_bounds__(kThreads) void k_gather_int2(const int2 *src, const int32_t *idx, int2 *dst, int k) {
     const int j = blockIdx.x * kThreads + threadIdx.x;
@@ -129,14 +137,20 @@ int loop_reset_subset(agx_loop *l, int k, float *d_obs, int32_t *d_loc, int32_t 
     LOOP_HIP(l, hipStreamWaitEvent(st, l->ev_r[rs], 0));
     if (h2d) *h2d += (int64_t)(6 * (size_t)N + (size_t)k * l->screen_bytes);
     if (gather) {
-        agx::RowCopyParams q;
-        q.src = reinterpret_cast<const uint4 *>(d_obs);
-        q.dst = reinterpret_cast<uint4 *>(l->d_final_obs);
-        q.idx = rmeta_idx(l->d_rmeta);
-        q.src_pitch16 = q.dst_pitch16 = (int64_t)(l->obs_row_floats / 4);
-        q.row16 = (int32_t)(l->obs_row_floats / 4);
-        q.gather = 1;
-        hipLaunchKernelGGL(agx::k_row_copy, dim3((q.row16 + kThreads - 1) / kThreads, k), dim3(kThreads), 0, st, q);
+        if (l->obs_row_floats % 4 == 0) {
+            agx::RowCopyParams q;
+            q.src = reinterpret_cast<const uint4 *>(d_obs);
+            q.dst = reinterpret_cast<uint4 *>(l->d_final_obs);
+            q.idx = rmeta_idx(l->d_rmeta);
+            q.src_pitch16 = q.dst_pitch16 = (int64_t)(l->obs_row_floats / 4);
+            q.row16 = (int32_t)(l->obs_row_floats / 4);
+            q.gather = 1;
+            hipLaunchKernelGGL(agx::k_row_copy, dim3((q.row16 + kThreads - 1) / kThreads, k), dim3(kThreads), 0, st, q);
+        } else {
+            const int64_t row32 = (int64_t)l->obs_row_floats;
+            hipLaunchKernelGGL(agx::k_row_gather32, dim3((unsigned)((row32 + kThreads - 1) / kThreads), k), dim3(kThreads), 0, st,
+                               reinterpret_cast<const uint32_t *>(d_obs), rmeta_idx(l->d_rmeta), reinterpret_cast<uint32_t *>(l->d_final_obs), row32);
+        }
         if (l->fovea && d_loc)
             hipLaunchKernelGGL(agx::k_gather_int2, dim3((k + kThreads - 1) / kThreads), dim3(kThreads), 0, st,
                                reinterpret_cast<const int2 *>(d_loc), rmeta_idx(l->d_rmeta), reinterpret_cast<int2 *>(l->d_final_loc), k);

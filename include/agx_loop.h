@@ -14,8 +14,10 @@
  *   reset (callback), packed reset screens uploaded and scattered, agx_ingest* (CLEAR), agx_fovea_reset, masked
  *   re-observation.
  *
- * Nothing here synchronises the device: the call returns when everything is enqueued; host outputs (reward, done,
- * ...) are complete at return, device outputs are ordered on `stream`.
+ * Nothing here synchronises the device or the caller's stream: the call returns when everything is enqueued; host
+ * outputs (reward, done, ...) are complete at return, device outputs are ordered on `stream`.  The only host waits
+ * are on the loop's own copies out of a pinned staging set before that set is overwritten - copies issued two steps
+ * (two resets) earlier - which is also what bounds how far the host can run ahead of the device: two steps.
  * The host source is a table of C callbacks, so libagx.so does not link the runner: active_gym/native_loop.py
  * fills it with the entry points of libagx_runner.so (agxr_step, agxr_reset_packed have exactly these signatures).
  */

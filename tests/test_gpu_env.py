@@ -612,6 +612,32 @@ def test_vec_env_on_a_device_that_is_not_the_current_one():
     b.close()
 
 
+def test_native_loop_gathers_terminal_rows_of_any_size():
+    """A raw-crop context with an odd fov size has observation rows that are not a multiple of 16 bytes (3 x 5 x 7 floats here): the
+    loop's gather of the terminal observations must not assume float4 rows.  Native loop == Python loop, every terminal observation."""
+    from active_gym import AtariEnvArgs, AtariVecEnv
+    N = 40
+    kw = dict(game="g", seed=3, obs_size=(84, 84), frame_stack=3, fov_size=(5, 7), fov_init_loc=(1, 2), sensory_action_mode="absolute",
+              resize_to_full=False, mask_out=False, frame_source="native", device="cuda:0", num_workers=2, scripted_actions=4,
+              scripted_lives=1, scripted_p_life=0, scripted_p_over=150)
+    a = AtariVecEnv(AtariEnvArgs(native_loop=True, **kw), N, kind="fixed", noop_fn=lambda: 2)
+    b = AtariVecEnv(AtariEnvArgs(native_loop=False, **kw), N, kind="fixed", noop_fn=lambda: 2)
+    assert a._loop is not None and b._loop is None and tuple(a.reset()[0].shape) == (N, 3, 5, 7)
+    b.reset()
+    rng = np.random.default_rng(0)
+    seen = 0
+    for step in range(12):
+        act = {"motor_action": rng.integers(0, 4, N), "sensory_action": rng.uniform(-5, 90, (N, 2)).astype(np.float32)}
+        ra, rb = a.step(act), b.step(act)
+        assert torch.equal(ra[0], rb[0]) and np.array_equal(ra[2], rb[2])
+        for i in np.nonzero(ra[2])[0]:
+            assert torch.equal(ra[4]["final_observation"][i], rb[4]["final_observation"][i]), (step, i)
+            seen += 1
+    assert seen >= 20
+    a.close()
+    b.close()
+
+
 @pytest.mark.parametrize("kind,fmt", [("fixed", "rgb"), ("flexible", "gray"), ("base", "gray")])
 def test_native_loop_equals_python_loop_at_scale(kind, fmt):
     """The native step loop (agx_loop_step) against the Python loop of vector.py, same native runner, same seeds, at a batch large
@@ -734,3 +760,30 @@ def test_c_loop_demo_matches_python_env(tmp_path):
             n_done += int(term.sum())
     assert n_done >= 10
     env.close()
+
+
+def test_host_outputs_through_pinned_buffers_equal_fresh_copies():
+    """args.copy_obs = False with host (NumPy) outputs: observations come back as views of two pinned host buffers used alternately
+    (no device-to-pageable copy per step): the same values as the default fresh arrays, and an observation survives exactly one
+    further step."""
+    from active_gym import AtariEnvArgs, AtariVecEnv
+    N = 6
+    kw = dict(game="g", seed=9, obs_size=(84, 84), fov_size=(30, 30), fov_init_loc=(0, 0), sensory_action_mode="absolute", resize_to_full=True,
+              frame_source="native", scripted_actions=4, scripted_lives=2, scripted_p_life=80, scripted_p_over=20, num_workers=2)
+    a = AtariVecEnv(AtariEnvArgs(**kw), N, kind="fixed", noop_fn=lambda: 1)
+    b = AtariVecEnv(AtariEnvArgs(copy_obs=False, **kw), N, kind="fixed", noop_fn=lambda: 1)
+    oa, ob = a.reset()[0], b.reset()[0]
+    assert isinstance(ob, np.ndarray) and np.array_equal(oa, ob)
+    rng = np.random.default_rng(2)
+    held = None
+    for step in range(10):
+        act = {"motor_action": rng.integers(0, 4, N), "sensory_action": rng.uniform(-5, 60, (N, 2))}
+        ra, rb = a.step(act), b.step(act)
+        assert np.array_equal(ra[0], rb[0]) and np.array_equal(ra[1], rb[1]) and np.array_equal(ra[2], rb[2]), step
+        if held is not None:
+            assert np.array_equal(held[0], held[1]), "an observation stays valid through the following step"
+        held = (rb[0], ra[0].copy())
+        for i in np.nonzero(ra[2])[0]:
+            assert np.array_equal(ra[4]["final_observation"][i], rb[4]["final_observation"][i])
+    a.close()
+    b.close()
