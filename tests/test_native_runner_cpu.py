@@ -10,6 +10,8 @@ import pytest
 from lcg_ale import LcgALE
 
 REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+# the screen rows cv2.resize reads for 210 -> 84 rows (agx_source_rows of an 84 x 84 context): y0 = floor(2.5 dy + 0.75), y0 + 1
+ROWS84 = np.array(sorted({int(np.floor((dy + 0.5) * 2.5 - 0.5)) + k for dy in range(84) for k in (0, 1)}), dtype=np.int32)
 
 
 def _build():
@@ -170,6 +172,24 @@ def test_ale_c_backend_through_a_stand_in_libale(tmp_path, monkeypatch):
             assert np.array_equal(py.reset(d, out=ra), nv.reset(d, out=rb)) and np.array_equal(ra, rb)
     assert dones >= 3
     nv.close(); py.close()
+    # compact staging through this backend: a real emulator renders its whole screen into a per-thread scratch buffer and the listed
+    # rows are copied out (Emulator::screen_rgb_rows / screen_gray_rows defaults) - RGB and the library's own grayscale screens
+    for fmt in ("rgb", "gray"):
+        common["frame_format"] = fmt
+        full = nr.NativeHostRunner(_Args(**common), N, workers=2, noop_fn=lambda: 4, backend="ale_c")
+        comp = nr.NativeHostRunner(_Args(**common), N, workers=2, noop_fn=lambda: 4, backend="ale_c", src_rows=ROWS84)
+        assert comp.frames.shape[2] == 168
+        assert np.array_equal(full.reset(), comp.reset()) and np.array_equal(full.frames[:, 0][:, ROWS84], comp.frames[:, 0])
+        for step in range(12):
+            m = rng.integers(0, 4, N)
+            a, b = full.step(m), comp.step(m)
+            for x, y in zip(a, b):
+                assert np.array_equal(x, y), (fmt, step)
+            for i in range(N):
+                for sl in range(int(a[2][i])):
+                    assert np.array_equal(full.frames[i, sl][ROWS84], comp.frames[i, sl]), (fmt, step, i, sl)
+        full.close(); comp.close()
+    common["frame_format"] = "rgb"
     with pytest.raises(RuntimeError, match="dlopen|symbol"):
         monkeypatch.setattr(nr, "_find_libale_c", lambda: (str(tmp_path / "missing.so"), fake))
         nr.NativeHostRunner(_Args(**common), 1, backend="ale_c")
@@ -206,9 +226,6 @@ def test_gray_frames_native_equals_python_runner():
             assert np.array_equal(py.reset(d, out=ra), nv.reset(d, out=rb)) and np.array_equal(ra, rb)
     py.close(); nv.close()
 
-
-# the screen rows cv2.resize reads for 210 -> 84 rows (agx_source_rows of an 84 x 84 context): y0 = floor(2.5 dy + 0.75), y0 + 1
-ROWS84 = np.array(sorted({int(np.floor((dy + 0.5) * 2.5 - 0.5)) + k for dy in range(84) for k in (0, 1)}), dtype=np.int32)
 
 
 @pytest.mark.parametrize("gray", [False, True])
