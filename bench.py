@@ -303,7 +303,9 @@ def run_e2e(dev, n, hc):
     torch.cuda.synchronize(dev)
     out["h2d_GBps"] = h.numel() * 5 / (time.perf_counter() - t0) / 1e9
     del h, d
-    act = {"motor_action": np.zeros(n, np.int64), "sensory_action": np.full((n, 2), 20.0, np.float32)}
+    # motor actions on the host (the emulators need them), sensory actions as a device tensor (a policy's output lives on the GPU:
+    # no per-step upload)
+    act = {"motor_action": np.zeros(n, np.int64), "sensory_action": torch.full((n, 2), 20.0, dtype=torch.float32, device=dev)}
     # Every repeat is a window of >= 0.35 s: the job's CPU quota is enforced per 100 ms period (CFS bandwidth control), and 2 x quota
     # busy emulator threads run unthrottled for only half of a period - a 40 ms window (what rounds 1-3 timed) catches either
     # the burst or the stall; three periods and more give the rate the box sustains.
