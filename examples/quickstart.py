@@ -21,8 +21,8 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--ale", action="store_true", help="use real ALE through atari_py / ale_py instead of the stand-in")
     ap.add_argument("--native", action="store_true",
-                    help="batched part: the C++ thread-per-core host runner (libagx_runner.so; scripted emulator, or real "
-                         "ALE with --ale) with grayscale screens and chunked H2D overlap")
+                    help="batched part: the C++ host runner (libagx_runner.so; scripted emulator, or real ALE with --ale) with "
+                         "grayscale screens under the native step loop (one C call per vector step, autoreset inside)")
     ap.add_argument("--envs", type=int, default=256)
     a = ap.parse_args()
     src = "ale" if a.ale else "synthetic"
@@ -46,7 +46,7 @@ def main():
     extra = {}
     if a.native:
         src = "native:ale" if a.ale else "native"
-        extra = dict(frame_format="gray", h2d_chunk_envs=max(1, a.envs // 8))
+        extra = dict(frame_format="gray")        # compact staging and the native step loop are the defaults of this path
     args = AtariEnvArgs(game="boxing", seed=0, obs_size=(84, 84), fov_size=(30, 30), fov_init_loc=(0, 0),
                         sensory_action_mode="relative", sensory_action_space=(-10.0, 10.0), resize_to_full=True,
                         frame_source=src, device="cuda", **extra)
@@ -60,7 +60,8 @@ def main():
         obs, rew, term, trunc, infos = venv.step(act)
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
-    print(f"vec env: {a.envs} envs, obs {tuple(obs.shape)} on {obs.device}; {a.envs * steps / dt:.0f} env steps/s end to end "
+    loop = "native step loop" if venv._loop is not None else "Python step loop"
+    print(f"vec env: {a.envs} envs, obs {tuple(obs.shape)} on {obs.device}; {a.envs * steps / dt:.0f} env steps/s end to end, {loop} "
           f"(host emulators + PCIe + kernels; frame source: {src}"
           + ("" if a.native else "; these emulators run in Python threads, try --native") + ")")
     venv.close()
