@@ -1225,11 +1225,16 @@ int agx_step_fixed(agx_ctx *ctx, const uint8_t *d_frames, const uint8_t *d_cmd, 
         pf.cmd = d_cmd;
         pf.phase = 1;
         pf.head = ctx->head[ctx->cur_head];                  // the head BEFORE this step's ingest
-        const size_t lds = std::max(ingest_lds(ctx), fixed_lds(c));
+        const bool b12 = ctx->tune.fused >= 2 && ctx->band12_ok && ctx->band_rows == 12;      // AGX_STEP_FUSED=2 / 3: band12 ingest body
+        const size_t lds = std::max(b12 ? band12_lds(ctx) : ingest_lds(ctx), fixed_lds(c));
         const dim3 grid1(pi.nbands + c.frame_stack, c.num_envs), grid2(1, c.num_envs), block(kThreads);
         using GS = GeomS<84, 84, 30, 30>;
         const GeomR gr{c.obs_h, c.obs_w, c.fov_h, c.fov_w};
-        if (headline)
+        if (b12 && headline && ctx->tune.fused == 3)
+            hipLaunchKernelGGL((k_step_fixed12_ff<GS>), grid1, block, lds, S(stream), GS{}, pi, pf);
+        else if (b12 && headline)
+            hipLaunchKernelGGL((k_step_fixed12<GS>), grid1, block, lds, S(stream), GS{}, pi, pf);
+        else if (headline)
             hipLaunchKernelGGL((k_step_fixed<GS>), grid1, block, lds, S(stream), GS{}, pi, pf);
         else
             hipLaunchKernelGGL((k_step_fixed<GeomR>), grid1, block, lds, S(stream), gr, pi, pf);

@@ -683,6 +683,27 @@ __global__ __launch_bounds__(kThreads) void k_step_fixed(G g, IngestParams pi, F
 }
 
 
+// the same with round 3's band12 ingest body (round 4 re-test: AGX_STEP_FUSED=2)
+template <class G>
+__global__ __launch_bounds__(kThreads) void k_step_fixed12(G g, IngestParams pi, FovParams pf) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int x = blockIdx.x, n = blockIdx.y;
+    if (x < pi.nbands)
+        ingest_band12<false>(pi, x, n, smem, (int)threadIdx.x);
+    else
+        fovea_fixed_body<G, AGX_OUT_RESIZE>(g, pf, x - pi.nbands, n, smem);
+}
+// ... and with the fovea workgroups FIRST in the grid (x < fs), so that the store-bound work is resident from the start of the launch
+template <class G>
+__global__ __launch_bounds__(kThreads) void k_step_fixed12_ff(G g, IngestParams pi, FovParams pf) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int x = blockIdx.x, n = blockIdx.y;
+    if (x >= pf.fs)
+        ingest_band12<false>(pi, x - pf.fs, n, smem, (int)threadIdx.x);
+    else
+        fovea_fixed_body<G, AGX_OUT_RESIZE>(g, pf, x, n, smem);
+}
+
 }  // namespace agx
 
 #include "agx_step_env.h"

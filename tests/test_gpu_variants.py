@@ -35,7 +35,7 @@ def test_experimental_forms_bit_identical_to_default_kernels():
     line = [l for l in r.stdout.splitlines() if l.startswith("VARIANTS_JSON ")][-1]
     rep = json.loads(line[len("VARIANTS_JSON "):])
     bad = {k: v for k, v in rep["variants"].items() if v != "ok"}
-    assert len(rep["variants"]) == 34 and not bad, bad          # 15 knob settings x 2 geometries + the packed wave form x 2 x 2
+    assert len(rep["variants"]) == 38 and not bad, bad          # 17 knob settings x 2 geometries + the packed wave form x 2 x 2
     # the shipped library's kernels produce exactly what the experiments build's default kernels produce
     import variants_child as vc
     from active_gym import _native as nat

@@ -18,7 +18,7 @@ KNOBS = ("AGX_PACKED_WAVE", "AGX_INGEST_NO_FULL", "AGX_INGEST_T", "AGX_INGEST_BA
          "AGX_STEP_FUSED", "AGX_STEP_SPLIT", "AGX_STEP_AUX_PRIO", "AGX_INGEST_PAIR12", "AGX_STEP_ENV")
 VARIANTS = [{"AGX_INGEST_T": "128"}, {"AGX_INGEST_BAND_ROWS": "7"}, {"AGX_INGEST_BAND_ROWS": "11"}, {"AGX_INGEST_PIPE": "2"},
             {"AGX_INGEST_PIPE": "7"}, {"AGX_INGEST_WAVE": "1"}, {"AGX_INGEST_NO_FULL": "1"}, {"AGX_INGEST_PAIR12": "1"},
-            {"AGX_FOVEA_PAIR": "1"}, {"AGX_STEP_FUSED": "1"}, {"AGX_STEP_SPLIT": "2"}, {"AGX_STEP_SPLIT": "3"}, {"AGX_STEP_ENV": "1"},
+            {"AGX_FOVEA_PAIR": "1"}, {"AGX_STEP_FUSED": "1"}, {"AGX_STEP_FUSED": "2"}, {"AGX_STEP_FUSED": "3"}, {"AGX_STEP_SPLIT": "2"}, {"AGX_STEP_SPLIT": "3"}, {"AGX_STEP_ENV": "1"},
             {"AGX_STEP_SPLIT": "4", "AGX_STEP_AUX_PRIO": "-1"}, {"AGX_INGEST_T": "128", "AGX_FOVEA_PAIR": "1"}]
 
 
