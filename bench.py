@@ -273,7 +273,10 @@ def cpu_baseline(budget_s, seed):
     return out
 
 
-def run_e2e(dev, n, hc):
+GAMES = ("breakout", "boxing", "pong", "seaquest", "qbert", "alien", "asterix", "freeway")      # configs[4]: one game per shard / GPU
+
+
+def run_e2e(dev, n, hc, rank=0):
     """PCIe- and emulator-inclusive rate through the drop-in API (never `value`): AtariVecEnv.step = native C++ host
     runner (scripted emulator, one thread per core) -> pinned staging (two sets, alternating) -> hipMemcpyAsync ->
     ingest + fovea -> device observations; RGB screens (the metric's input format, north_star) and ALE grayscale screens (what the
@@ -311,11 +314,14 @@ def run_e2e(dev, n, hc):
     # the burst or the stall; three periods and more give the rate the box sustains.
     window_s = 0.35
     for fmt in ("rgb", "gray"):
-        args = AtariEnvArgs(frame_format=fmt, game="breakout", seed=1, obs_size=(84, 84), fov_size=(30, 30), fov_init_loc=(0, 0),
+        from active_gym.sharding import shard_game
+        game = shard_game(list(GAMES), rank)              # rank g plays GAMES[g % 8] (the game only selects the emulator, never a shape)
+        args = AtariEnvArgs(frame_format=fmt, game=game, seed=1 + 100003 * rank, obs_size=(84, 84), fov_size=(30, 30), fov_init_loc=(0, 0),
                             sensory_action_mode="absolute", resize_to_full=True, frame_source="native", device=str(dev),
                             num_workers=workers, h2d_chunk_envs=0, scripted_lives=3, scripted_p_life=6, scripted_p_over=1)
         env = AtariVecEnv(args, n, kind="fixed")
         plan = env.host_plan
+        out["game"] = game
         out["placement"] = {"numa_node": plan["numa_node"], "workers": env.runner.num_workers, "pinned_cpus": sorted(set(env.runner.worker_cpus)),
                             "cpus_usable": plan["usable"], "per_rank_default": plan["per_rank"],
                             "staging": "pinned buffers allocated while bound to the rank's CPUs (first touch on the GPU's NUMA node)"}
@@ -600,7 +606,7 @@ def main():
     if not args.no_e2e:
         barrier(dist, local_rank)
         try:
-            e2e_mine = run_e2e(dev, n, host_cores())
+            e2e_mine = run_e2e(dev, n, host_cores(), rank)
         except Exception as ex:  # noqa: BLE001 - a reported extra, never the metric
             e2e_mine = {"error": repr(ex)}
     e2e_all = [e2e_mine]
@@ -684,6 +690,10 @@ def main():
                 out["e2e"] = e2e_all[0]
             else:
                 out["e2e_per_rank"] = e2e_all
+                ok = [x for x in e2e_all if isinstance(x, dict) and "error" not in x]
+                out["e2e_aggregate"] = {fmt: {"env_steps_per_s_median": sum(x[fmt]["env_steps_per_s_median"] for x in ok),
+                                              "env_steps_per_s_best": sum(x[fmt]["env_steps_per_s"] for x in ok)} for fmt in ("rgb", "gray")}
+                out["e2e_aggregate"]["ranks"] = len(ok)
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args.cpu_seconds, 1234)
         print(json.dumps(out), flush=True)

@@ -101,6 +101,9 @@ def test_bench_two_gpu_rehearsal_prints_one_line_with_per_gpu_values():
     cpus = [set(x["placement"]["pinned_cpus"]) for x in e]
     assert cpus[0] and cpus[1] and not (cpus[0] & cpus[1]), cpus
     assert all(x["placement"]["workers"] == x["workers"] for x in e)
+    assert [x["game"] for x in e] == ["breakout", "boxing"]                      # configs[4]: one game per shard
+    agg = d["e2e_aggregate"]
+    assert agg["ranks"] == 2 and abs(agg["rgb"]["env_steps_per_s_median"] - sum(x["rgb"]["env_steps_per_s_median"] for x in e)) < 1e-6
 
 
 def test_bench_single_rank_over_rccl():
