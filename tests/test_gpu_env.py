@@ -787,3 +787,49 @@ def test_host_outputs_through_pinned_buffers_equal_fresh_copies():
             assert np.array_equal(ra[4]["final_observation"][i], rb[4]["final_observation"][i])
     a.close()
     b.close()
+
+
+@pytest.mark.parametrize("fmt", ["rgb", "gray"])
+def test_native_loop_running_ahead_of_the_device_matches_a_synchronous_run(fmt):
+    """The step loop never synchronises the device: the host runs up to two steps ahead, emulators overwrite one pinned staging set
+    while the copy of the other is in flight, reset uploads slot in between step uploads on the copy stream.  A wrong event edge would
+    show as a stale or half-written screen in SOME step of a long asynchronous run.  150 steps at N = 512 with resets in every step, no
+    synchronisation inside the loop (observations are cloned on the stream), against the same envs stepped by the Python loop with a
+    synchronisation after every step."""
+    import zlib
+    from active_gym import AtariEnvArgs, AtariVecEnv
+    N, STEPS = 512, 150
+    kw = dict(game="g", seed=4, obs_size=(84, 84), fov_size=(30, 30), fov_init_loc=(0, 0), sensory_action_mode="absolute",
+              resize_to_full=False, mask_out=True, frame_source="native", frame_format=fmt, device="cuda:0", num_workers=6,
+              scripted_actions=4, scripted_lives=3, scripted_p_life=20, scripted_p_over=4)
+    rng = np.random.default_rng(8)
+    motors = rng.integers(0, 4, (STEPS, N))
+    sens = torch.from_numpy(rng.uniform(-5, 60, (STEPS, N, 2)).astype(np.float32)).to("cuda:0")
+
+    def run(loop, sync):
+        import random
+        rnd = random.Random(17)
+        env = AtariVecEnv(AtariEnvArgs(native_loop=loop, **kw), N, kind="fixed", noop_fn=lambda: rnd.randrange(30))
+        assert (env._loop is not None) == loop
+        obs0, _ = env.reset()
+        outs, dones, fins = [obs0.clone()], [], []
+        for t in range(STEPS):
+            o, r, d, tr, info = env.step({"motor_action": motors[t], "sensory_action": sens[t]})
+            outs.append(o.clone())                  # device-side copy in stream order: no host synchronisation
+            dones.append(d.copy())
+            fins.append([info["final_observation"][i] for i in np.nonzero(d)[0]] if d.any() else [])
+            if sync:
+                torch.cuda.synchronize()
+        torch.cuda.synchronize()
+        crc = [zlib.crc32(o.cpu().numpy().tobytes()) for o in outs]
+        fcrc = [[zlib.crc32(f.cpu().numpy().tobytes()) for f in fl] for fl in fins]
+        env.close()
+        return crc, np.array(dones), fcrc
+
+    a = run(True, False)
+    b = run(False, True)
+    assert np.array_equal(a[1], b[1])
+    bad = [t for t in range(STEPS + 1) if a[0][t] != b[0][t]]
+    assert not bad, f"observations differ at steps {bad[:10]}"
+    assert a[2] == b[2]
+    assert a[1].any(axis=1).mean() > 0.9, "resets should occur in nearly every step"
