@@ -39,10 +39,6 @@ struct agx_ctx {
     std::vector<int32_t> src_rows;
     int4 *in_ytab_c = nullptr;
     bool compact12_ok = false;
-    // K1g direct form (agx_k1_direct.h): band12_ok, x0 affine, and the tap pairs of every two adjacent output pixels inside one
-    // 8-byte window at the dword of the first one's x0 (pulled back into the row)
-    bool direct_ok = false;
-    int x_mul = 0, x_add = 0, x_shift = 0;
     Tap *fx_xtab = nullptr;    // K2 tables
     Tap *fx_ytab = nullptr;
     int2 *per_ln[4] = {nullptr, nullptr, nullptr, nullptr};   // K3 tables
@@ -85,7 +81,6 @@ struct agx_ctx {
     struct Tune {
         int generic = 0;         // AGX_FOVEA_GENERIC     K3 / K4 through the generic fallback kernel
         int no_full = 0;         // AGX_INGEST_NO_FULL    general k_ingest<256> even where k_ingest_full12 applies
-        int no_direct = 0;       // AGX_INGEST_NO_DIRECT  gray screens through the band forms even where the direct form applies
         int flex_v2 = 0;         // AGX_FLEX_V2           K4 through k_fovea_flexible2 (pass-by-pass form)
         int per_v2 = 0;          // AGX_PER_V2            K3 through k_fovea_peripheral2
         // ---- experiments build only (always 0 in libagx.so)
@@ -442,7 +437,6 @@ int agx_create(const agx_config *cfg, agx_ctx **out) {
     ctx->cfg = c;
     ctx->tune.generic = env_int("AGX_FOVEA_GENERIC");
     ctx->tune.no_full = env_int("AGX_INGEST_NO_FULL");
-    ctx->tune.no_direct = env_int("AGX_INGEST_NO_DIRECT");
     ctx->tune.flex_v2 = env_int("AGX_FLEX_V2");
     ctx->tune.per_v2 = env_int("AGX_PER_V2");
 #ifdef AGX_EXPERIMENTS
@@ -540,27 +534,6 @@ int agx_create(const agx_config *cfg, agx_ctx **out) {
         for (int i = 0; i < c.obs_w && ctx->band12_ok; ++i)
             if (((2 * x0[i]) & ~3) + 8 > 2 * kRawW + 8) ctx->band12_ok = false;
         ctx->compact12_ok = ctx->band12_ok && pairs;
-        // direct gray form: an exact integer form of x0 and the window property
-        bool x_affine = false;
-        for (int sh = 0; sh <= 12 && !x_affine; ++sh) {
-            const long mul = std::lround((double)kRawW / c.obs_w * (double)(1 << sh));
-            for (long add = -(1L << sh); add <= (1L << (sh + 1)) && !x_affine; ++add) {
-                bool ok = mul > 0 && mul * c.obs_w + std::labs(add) < (1L << 24);
-                for (int i = 0; i < c.obs_w && ok; ++i) ok = ((i * mul + add) >> sh) == x0[i] && i * mul + add >= 0;
-                if (ok) {
-                    x_affine = true;
-                    ctx->x_mul = (int)mul;
-                    ctx->x_add = (int)add;
-                    ctx->x_shift = sh;
-                }
-            }
-        }
-        ctx->direct_ok = ctx->band12_ok && x_affine && c.obs_w % 4 == 0 && kRawW >= 8;
-        for (int i = 0; i < c.obs_w && ctx->direct_ok; ++i) {
-            const int xb = std::min(x0[i & ~1] & ~3, kRawW - 8);
-            const int o = x0[i] - xb;
-            if (o < 0 || o + 1 > 7) ctx->direct_ok = false;
-        }
         // ingest workgroup: T threads produce band_rows output rows (band_rows * ow/4 <= T and the
         // 2 * band_rows row jobs fit the T/40 loader groups x 4 iterations).  128-thread workgroups give
         // 16 independent workgroups per CU whose load / compute phases interleave (AGX_INGEST_T tunes).
@@ -765,9 +738,6 @@ static IngestParams ingest_params(agx_ctx *ctx, const uint8_t *d_frames, const u
     p.ytab12 = ctx->in_ytab12;
     p.ow4_inv16 = (65536 + c.obs_w / 4 - 1) / (c.obs_w / 4);
     p.src_rows = 0;
-    p.x_mul = ctx->x_mul;
-    p.x_add = ctx->x_add;
-    p.x_shift = ctx->x_shift;
     p.stamps = nullptr;
 #ifdef AGX_STAMPS
     if (const char *e = getenv("AGX_DBG_PTR")) p.stamps = reinterpret_cast<unsigned long long *>(strtoull(e, nullptr, 0));
@@ -849,9 +819,7 @@ int agx_ingest_gray_raw(agx_ctx *ctx, const uint8_t *d_gray, const uint8_t *d_cm
     p.band_rows = std::min(br, ctx->band_rows > 0 && ctx->ingest_t == 256 ? ctx->band_rows : br);
     p.nbands = (c.obs_h + p.band_rows - 1) / p.band_rows;
     const size_t lds = sizeof(int4) * p.band_rows + sizeof(int2) * c.obs_w + (size_t)2 * p.band_rows * 2 * kRawW;
-    if (ctx->tune.no_full == 0 && ctx->tune.no_direct == 0 && ctx->direct_ok && p.band_rows == 12)
-        AGX_LAUNCH(0, k_ingest_grayraw_direct, dim3(p.nbands, c.num_envs), dim3(kThreads), 0, S(stream), p);
-    else if (ctx->tune.no_full == 0 && ctx->band12_ok && p.band_rows == 12)
+    if (ctx->tune.no_full == 0 && ctx->band12_ok && p.band_rows == 12)
         AGX_LAUNCH(0, k_ingest_grayraw_full12, dim3(p.nbands, c.num_envs), dim3(kThreads), band12_lds(ctx), S(stream), p);
     else
         AGX_LAUNCH(0, k_ingest_grayraw, dim3(p.nbands, c.num_envs), dim3(kThreads), lds, S(stream), p);
@@ -885,9 +853,7 @@ static int ingest_compact(agx_ctx *ctx, const uint8_t *d_rows, const uint8_t *d_
     p.nbands = (c.obs_h + br - 1) / br;
     const size_t lds = sizeof(int4) * br + sizeof(int2) * c.obs_w + (size_t)2 * br * 2 * kRawW;
     const dim3 grid(p.nbands, c.num_envs), block(kThreads);
-    if (gray && ctx->tune.no_full == 0 && ctx->tune.no_direct == 0 && ctx->direct_ok && ctx->compact12_ok && br == 12) {
-        AGX_LAUNCH(0, k_ingest_grayraw_direct_compact, grid, block, 0, S(stream), p);
-    } else if (ctx->tune.no_full == 0 && ctx->compact12_ok && br == 12) {
+    if (ctx->tune.no_full == 0 && ctx->compact12_ok && br == 12) {
         if (gray) AGX_LAUNCH(0, k_ingest_grayraw_full12_compact, grid, block, band12_lds(ctx), S(stream), p);
         else AGX_LAUNCH(0, k_ingest_full12_compact, grid, block, band12_lds(ctx), S(stream), p);
     } else {

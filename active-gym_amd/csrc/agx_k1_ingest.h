@@ -114,8 +114,6 @@ struct IngestParams {
     // ascending order - u8 [N][2][src_rows][160][3] (gray: [N][2][src_rows][160]).  `ytab` then holds PACKED row indices;
     // the band12 form needs every (y0, y1) pair disjoint and ascending, so that output row dy reads packed rows 2 dy, 2 dy + 1.
     int32_t src_rows;
-    // direct gray form (agx_k1_direct.h): x0(dx) == (dx * x_mul + x_add) >> x_shift for every dx (checked at agx_create)
-    int32_t x_mul, x_add, x_shift;
     unsigned long long *stamps;   // diagnostic builds only (AGX_STAMPS): [workgroup][wave][8] records
 };
 

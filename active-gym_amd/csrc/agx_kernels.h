@@ -2,7 +2,6 @@
 // byte/float streaming work: no MFMA anywhere, there is no dense contraction).
 //
 //   k_ingest            K1  RGB -> ALE luminance -> OpenCV fixed-point bilinear -> 2-frame max -> u8 ring slot
-//   k_ingest_grayraw*   K1g ALE grayscale screens in: band forms (agx_k1_ingest.h) and the LDS-free direct form (agx_k1_direct.h)
 //   k_ingest_gray       K1' same append from already obs-sized gray frames
 //   k_ingest_rgb        K1b DMC front end: obs-sized RGB -> cv2 BGR2GRAY fixed point -> ring slot (no max, no resize)
 //   k_stack_u8 / k_full K0  ring -> stack order (u8 / f32 k/255)
@@ -18,7 +17,6 @@
 #include "agx_common.h"
 #include "agx_k0_stack.h"
 #include "agx_k1_ingest.h"
-#include "agx_k1_direct.h"
 #include "agx_fov_common.h"
 #include "agx_k2_fixed.h"
 #include "agx_k34_resample.h"

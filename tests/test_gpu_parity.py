@@ -681,42 +681,6 @@ def test_general_ingest_kernel_matches_band12(dev, obs, monkeypatch):
     g.close()
 
 
-@pytest.mark.parametrize("compact", [False, True])
-@pytest.mark.parametrize("knob", ["AGX_INGEST_NO_DIRECT", "AGX_INGEST_NO_FULL"])
-def test_gray_band_kernels_match_the_direct_form(dev, knob, compact, monkeypatch):
-    """Grayscale screens of the headline geometry go through the LDS-free direct form (agx_k1_direct.h); AGX_INGEST_NO_DIRECT
-    routes them through the band12 form, AGX_INGEST_NO_FULL through the general band kernel (what other geometries get): same
-    ring bit for bit, whole and compact screens, with clears, skips and short steps - and the last env's last row window (the
-    one pulled back into the row) filled with its own values."""
-    N, fs = 23, 4
-    kw = dict(num_envs=N, kind="base", obs_size=(84, 84), frame_stack=fs)
-    for k_ in ("AGX_INGEST_NO_DIRECT", "AGX_INGEST_NO_FULL"):
-        monkeypatch.delenv(k_, raising=False)
-    d = _pipe(**kw)
-    monkeypatch.setenv(knob, "1")
-    g = _pipe(**kw)
-    rows = d.source_rows()
-    rng = np.random.default_rng(17 + compact)
-    for step in range(6):
-        gray = rng.integers(0, 256, (N, 2, 210, 160), dtype=np.uint8)
-        gray[:, :, :, 150:] = rng.integers(0, 256, (N, 2, 210, 10), dtype=np.uint8) | 1
-        nvalid = rng.integers(0, 3, N)
-        clear = (rng.random(N) < 0.2).astype(np.uint8)
-        skip = (rng.random(N) < 0.15).astype(np.uint8)
-        nvalid[clear == 1] = 1
-        cmd = _t((nvalid | clear * 4 | skip * 8).astype(np.uint8), dev)
-        if compact:
-            comp = _t(np.ascontiguousarray(gray[:, :, rows]), dev)
-            d.ingest_gray_raw_compact(comp, cmd)
-            g.ingest_gray_raw_compact(comp, cmd)
-        else:
-            d.ingest_gray_raw(_t(gray, dev), cmd)
-            g.ingest_gray_raw(_t(gray, dev), cmd)
-        assert torch.equal(d.stack_u8(), g.stack_u8()), step
-    d.close()
-    g.close()
-
-
 @pytest.mark.parametrize("knob", ["AGX_FOVEA_GENERIC", "V2"])
 @pytest.mark.parametrize("kind", ["peripheral", "flexible"])
 def test_generic_fallback_kernel_matches_tuned(dev, kind, knob, monkeypatch):

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Full-size identity check of an experimental ingest form against the shipped one: N = 1024, six steps, ring bytes compared.
-    AGX_CHECK_ENV="AGX_INGEST_STREAM=1792" python tools/check_stream.py"""
+    AGX_CHECK_ENV="AGX_INGEST_NO_FULL=1" python tools/check_stream.py      (any knob agx_create reads; round 3: AGX_INGEST_STREAM=1792)"""
 import os, sys
 sys.path[:0] = [os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "active-gym_amd")]
 import torch
@@ -9,7 +9,7 @@ dev = torch.device("cuda:0")
 N = int(os.environ.get("N", 1024))
 kw = dict(num_envs=N, kind="fixed", fov_size=(30, 30), resize_to_full=True, device=dev)
 a = ObsPipeline(**kw)
-k, v = os.environ.get("AGX_CHECK_ENV", "AGX_INGEST_STREAM=1792").split("=")
+k, v = os.environ.get("AGX_CHECK_ENV", "AGX_INGEST_NO_FULL=1").split("=")
 os.environ[k] = v
 b = ObsPipeline(**kw)
 del os.environ[k]
