@@ -89,11 +89,14 @@ class NativeStepLoop:
             raise nat.AgxError(rc, (self._lib.agx_loop_last_error(None) or b"").decode())
         self.n = pipe.num_envs
         self._motor = np.zeros(self.n, np.int32)
+        self._motor_ptr = self._motor.ctypes.data
+        self._views = {}
         self._res = AgxLoopResult()
         self._cb_error = None
 
     def close(self):
         if getattr(self, "_h", None) is not None and self._h.value:
+            self._views = {}                                       # views of buffers that are about to be freed
             self._lib.agx_loop_destroy(self._h)
             self._h = _P()
 
@@ -149,19 +152,38 @@ class NativeStepLoop:
         final_res | None) - host arrays are copies, device tensors are views of loop-owned buffers valid until the next step."""
         self._motor[:] = motor
         r = self._res
-        self._check(self._lib.agx_loop_step(self._h, self._motor.ctypes.data, self._ptr(action), int(action_dt), self._ptr(action_type),
+        self._check(self._lib.agx_loop_step(self._h, self._motor_ptr, self._ptr(action), int(action_dt), self._ptr(action_type),
                                             self._ptr(obs), self._ptr(loc), self._ptr(res), C.byref(r), self._stream()))
         n, k = self.n, int(r.n_done)
-        reward = np.ctypeslib.as_array(r.reward, shape=(n,)).copy()
-        raw = np.ctypeslib.as_array(r.raw, shape=(n,)).copy()
-        done = np.ctypeslib.as_array(r.done, shape=(n,)).astype(bool)
-        idx = np.ctypeslib.as_array(r.done_idx, shape=(k,)).copy() if k else np.zeros(0, np.int32)
+        reward = self._host("reward", r.reward, np.float64).copy()
+        raw = self._host("raw", r.raw, np.float64).copy()
+        done = self._host("done", r.done, np.uint8).astype(bool)
+        idx = self._host("done_idx", r.done_idx, np.int32)[:k].copy() if k else np.zeros(0, np.int32)
         fo = fl = fr = None
         if k and r.d_final_obs:
-            fo = _view(r.d_final_obs, (k,) + tuple(obs.shape[1:]), "<f4", self.device)
+            fo = self._device("final_obs", r.d_final_obs, (n,) + tuple(obs.shape[1:]), "<f4")[:k]
             if r.d_final_loc:
-                fl = _view(r.d_final_loc, (k, 2), "<i4", self.device)
+                fl = self._device("final_loc", r.d_final_loc, (n, 2), "<i4")[:k]
             if r.d_final_res:
-                fr = _view(r.d_final_res, (k, 2), "<i4", self.device)
+                fr = self._device("final_res", r.d_final_res, (n, 2), "<i4")[:k]
         self.h2d_bytes = int(r.h2d_bytes)
         return reward, raw, done, idx, fo, fl, fr
+
+    # The loop's result arrays and side buffers are allocated once in agx_loop_create and never move: ONE NumPy / torch view per
+    # buffer, made at first use and sliced per step.  (A view per step would leak: a tensor made from __cuda_array_interface__
+    # keeps its source object alive for good - 180 B per view, found by tools/soak.py - and np.ctypeslib.as_array builds a ctypes
+    # type per distinct length.)
+    def _host(self, name, ptr, dtype):
+        addr = C.cast(ptr, C.c_void_p).value
+        hit = self._views.get(name)
+        if hit is None or hit[0] != addr:
+            buf = (C.c_char * (self.n * np.dtype(dtype).itemsize)).from_address(addr)
+            hit = self._views[name] = (addr, np.frombuffer(buf, dtype=dtype, count=self.n))
+        return hit[1]
+
+    def _device(self, name, ptr, shape, typestr):
+        addr = int(ptr)
+        hit = self._views.get(name)
+        if hit is None or hit[0] != addr or tuple(hit[1].shape) != tuple(shape):
+            hit = self._views[name] = (addr, _view(addr, shape, typestr, self.device))
+        return hit[1]

@@ -1,0 +1,73 @@
+#!/usr/bin/env python3
+"""Soak: AtariVecEnv on the native runner for a time budget per configuration, with episode ends (autoreset) in every step - host RSS, device
+memory in use (hipMemGetInfo through torch) and steps/s sampled along the way.  A step call allocates nothing on the native loop and only
+its outputs' Python objects on the Python loop, so all three must be flat after the first sample.
+
+    python tools/soak.py [seconds per configuration = 60]
+"""
+import os
+import resource
+import sys
+import time
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path[:0] = [os.path.join(REPO, "active-gym_amd")]
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+
+from active_gym import AtariEnvArgs, AtariVecEnv  # noqa: E402
+
+budget = float(sys.argv[1]) if len(sys.argv) > 1 else 60.0
+dev = torch.device("cuda:0")
+N = 256
+
+
+def rss_mb():
+    with open("/proc/self/statm") as f:
+        return int(f.read().split()[1]) * resource.getpagesize() / 1e6
+
+
+def used_mb():
+    free, total = torch.cuda.mem_get_info(dev)
+    return (total - free) / 1e6
+
+
+worst = 0.0
+for kind, fmt, native_loop, out in (("fixed", "gray", True, "device"), ("flexible", "rgb", True, "device"), ("peripheral", "gray", False, "device"),
+                                    ("fixed", "gray", False, "numpy")):
+    kw = {}
+    if out == "device":
+        kw["device"] = str(dev)
+    args = AtariEnvArgs(game="boxing", seed=3, obs_size=(84, 84), fov_size=(30, 30), fov_init_loc=(0, 0), sensory_action_mode="absolute",
+                        resize_to_full=True, frame_source="native", frame_format=fmt, scripted_lives=3, scripted_p_life=20, scripted_p_over=5,
+                        native_loop=native_loop, **({"peripheral_res": (20, 20)} if kind == "peripheral" else {}), **kw)
+    env = AtariVecEnv(args, N, kind=kind)
+    env.reset()
+    act = {"motor_action": np.zeros(N, np.int64), "sensory_action": np.full((N, 2), 20.0, np.float32)}
+    if kind == "flexible":
+        act["sensory_action_type"] = np.zeros(N, np.int64)
+    for _ in range(200):
+        env.step(act)
+    torch.cuda.synchronize(dev)
+    base = (rss_mb(), used_mb())
+    t0 = t_last = time.perf_counter()
+    steps = dones = 0
+    samples = []
+    while time.perf_counter() - t0 < budget:
+        for _ in range(500):
+            dones += int(env.step(act)[2].sum())
+        steps += 500
+        torch.cuda.synchronize(dev)
+        now = time.perf_counter()
+        samples.append((steps, rss_mb() - base[0], used_mb() - base[1], 500 * N / (now - t_last)))
+        t_last = now
+    env.close()
+    name = f"{kind:10s} {fmt:4s} {'native loop' if native_loop else 'python loop'} {out:6s}"
+    d_rss = samples[-1][1] - samples[len(samples) // 4][1]
+    d_dev = samples[-1][2] - samples[len(samples) // 4][2]
+    worst = max(worst, d_rss, d_dev)
+    print(f"{name}: {steps} steps, {dones} episode ends; host RSS vs start {samples[len(samples) // 4][1]:+.1f} MB at a quarter -> {samples[-1][1]:+.1f} MB at the end;"
+          f" device memory {samples[len(samples) // 4][2]:+.1f} -> {samples[-1][2]:+.1f} MB; env steps/s first / last sample {samples[0][3] / 1e3:.0f} k / {samples[-1][3] / 1e3:.0f} k",
+          flush=True)
+print("growth over the last three quarters of any run: %.1f MB" % worst)
+sys.exit(1 if worst > 64 else 0)
