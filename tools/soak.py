@@ -1,7 +1,10 @@
 #!/usr/bin/env python3
 """Soak: AtariVecEnv on the native runner for a time budget per configuration, with episode ends (autoreset) in every step - host RSS, device
 memory in use (hipMemGetInfo through torch) and steps/s sampled along the way.  A step call allocates nothing on the native loop and only
-its outputs' Python objects on the Python loop, so all three must be flat after the first sample.
+its outputs' Python objects on the Python loop, so all three must be flat.  The baseline is taken after 1,500 warm-up steps: the first
+few hundred steps with episode ends of the FIRST env of a process grow the process heap once by ~190 MB (host-side pools of the HIP runtime
+under the loop's run-ahead; a second env in the same process does not repeat it, and the memory is reused after close) - printed as
+"warm-up", not counted as growth.
 
     python tools/soak.py [seconds per configuration = 60]
 """
@@ -46,10 +49,12 @@ for kind, fmt, native_loop, out in (("fixed", "gray", True, "device"), ("flexibl
     act = {"motor_action": np.zeros(N, np.int64), "sensory_action": np.full((N, 2), 20.0, np.float32)}
     if kind == "flexible":
         act["sensory_action_type"] = np.zeros(N, np.int64)
-    for _ in range(200):
+    r0 = rss_mb()
+    for _ in range(1500):                   # incl. the process's one-time heap growth (see the docstring)
         env.step(act)
     torch.cuda.synchronize(dev)
     base = (rss_mb(), used_mb())
+    warm = base[0] - r0
     t0 = t_last = time.perf_counter()
     steps = dones = 0
     samples = []
@@ -66,7 +71,7 @@ for kind, fmt, native_loop, out in (("fixed", "gray", True, "device"), ("flexibl
     d_rss = samples[-1][1] - samples[len(samples) // 4][1]
     d_dev = samples[-1][2] - samples[len(samples) // 4][2]
     worst = max(worst, d_rss, d_dev)
-    print(f"{name}: {steps} steps, {dones} episode ends; host RSS vs start {samples[len(samples) // 4][1]:+.1f} MB at a quarter -> {samples[-1][1]:+.1f} MB at the end;"
+    print(f"{name}: warm-up {warm:+.1f} MB; {steps} steps, {dones} episode ends; host RSS vs start {samples[len(samples) // 4][1]:+.1f} MB at a quarter -> {samples[-1][1]:+.1f} MB at the end;"
           f" device memory {samples[len(samples) // 4][2]:+.1f} -> {samples[-1][2]:+.1f} MB; env steps/s first / last sample {samples[0][3] / 1e3:.0f} k / {samples[-1][3] / 1e3:.0f} k",
           flush=True)
 print("growth over the last three quarters of any run: %.1f MB" % worst)
