@@ -15,7 +15,7 @@ from . import _native as nat
 from .frame_source import RAW_H, RAW_W, resolve_frame_format
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(os.path.dirname(_HERE), "lib", "libagx_runner.so")
+LIB_PATH = os.environ.get("AGXR_LIB") or os.path.join(os.path.dirname(_HERE), "lib", "libagx_runner.so")     # AGXR_LIB: a sanitizer build (tools/README.md)
 
 
 class AgxrConfig(C.Structure):

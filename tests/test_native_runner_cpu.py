@@ -301,3 +301,31 @@ def test_workers_are_pinned_to_the_listed_cpus():
     d = NativeHostRunner(_Args(**common), 2, backend="scripted")
     assert d.num_workers == min(2, d._lib.agxr_default_threads())
     d.close()
+
+
+@pytest.mark.parametrize("sanitizer,args", [("thread", ["36", "13"]), ("address,undefined", ["120", "23"])])
+def test_runner_under_sanitizers(tmp_path, sanitizer, args):
+    """csrc/agx_runner.cpp compiled with ThreadSanitizer / AddressSanitizer + UBSan into tests/runner_sanitizer_harness.cpp and driven
+    from plain C++ (no Python in the process, so every report is the runner's): blocking and chunked steps, full and packed resets,
+    render, state queries, whole / compact and RGB / gray staging, 1 / 3 / 8 worker threads - no report, and the same checksum for
+    every thread count."""
+    import shutil
+    import subprocess
+    if shutil.which("g++") is None:
+        pytest.skip("no g++")
+    exe = tmp_path / "harness"
+    cmd = ["g++", "-O1", "-g", "-fno-omit-frame-pointer", f"-fsanitize={sanitizer}", "-mavx2", "-ffp-contract=off", "-std=c++17",
+           "-I", os.path.join(REPO, "include"), os.path.join(REPO, "tests", "runner_sanitizer_harness.cpp"),
+           os.path.join(REPO, "active-gym_amd", "csrc", "agx_runner.cpp"), "-o", str(exe), "-pthread", "-ldl"]
+    b = subprocess.run(cmd, capture_output=True, text=True)
+    if b.returncode != 0 and "sanitizer" in b.stderr.lower() and "cannot find" in b.stderr.lower():
+        pytest.skip("sanitizer runtime not installed: " + b.stderr[-200:])
+    assert b.returncode == 0, b.stderr[-2000:]
+    env = dict(os.environ, TSAN_OPTIONS="halt_on_error=1 exitcode=66", ASAN_OPTIONS="halt_on_error=1 detect_leaks=1 exitcode=67",
+               UBSAN_OPTIONS="halt_on_error=1 print_stacktrace=1 exitcode=68")
+    env.pop("LD_PRELOAD", None)
+    r = subprocess.run([str(exe)] + args, capture_output=True, text=True, env=env, timeout=600)
+    assert r.returncode == 0, (r.returncode, r.stdout[-1500:], r.stderr[-3000:])
+    assert "Sanitizer" not in r.stderr and "runtime error" not in r.stderr, r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("gray=")]
+    assert len(lines) == 12 and not any("DIFFERS" in ln for ln in lines), r.stdout
