@@ -2,9 +2,9 @@
 """Soak: AtariVecEnv on the native runner for a time budget per configuration, with episode ends (autoreset) in every step - host RSS, device
 memory in use (hipMemGetInfo through torch) and steps/s sampled along the way.  A step call allocates nothing on the native loop and only
 its outputs' Python objects on the Python loop, so all three must be flat.  The baseline is taken after 1,500 warm-up steps: the first
-few hundred steps with episode ends of the FIRST env of a process grow the process heap once by ~190 MB (host-side pools of the HIP runtime
-under the loop's run-ahead; a second env in the same process does not repeat it, and the memory is reused after close) - printed as
-"warm-up", not counted as growth.
+few hundred steps of the first env of a process grow its RSS once by ~190 MB under either step loop - not in the malloc arena (mallinfo2
+stays flat, profiles/r04_soak_heap_stats.txt: a mapping of the HIP runtime's own), not repeated by a second env in the same process -
+printed as "warm-up", not counted as growth.
 
     python tools/soak.py [seconds per configuration = 60]
 """
