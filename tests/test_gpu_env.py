@@ -638,17 +638,18 @@ def test_native_loop_gathers_terminal_rows_of_any_size():
     b.close()
 
 
-@pytest.mark.parametrize("kind,fmt", [("fixed", "rgb"), ("flexible", "gray"), ("base", "gray")])
-def test_native_loop_equals_python_loop_at_scale(kind, fmt):
+@pytest.mark.parametrize("kind,fmt,N,STEPS", [("fixed", "rgb", 700, 14), ("flexible", "gray", 700, 14), ("base", "gray", 700, 14),
+                                              ("fixed", "rgb", 4096, 4)])
+def test_native_loop_equals_python_loop_at_scale(kind, fmt, N, STEPS):
     """The native step loop (agx_loop_step) against the Python loop of vector.py, same native runner, same seeds, at a batch large
     enough for what the N = 5 oracle chains never reach: several hundred envs ending an episode in ONE step (the gathers and the
     scatter run with grid.y = k in the hundreds), more done envs than a 256-env scan block, every step with resets.  Everything the
-    step returns must be identical: observations, rewards, terminals, counters, fov state, every terminal observation / info."""
+    step returns must be identical: observations, rewards, terminals, counters, fov state, every terminal observation / info.
+    N = 4096: four times the metric's batch - 330 MB of compact screens per step, ~ 2,000 episode ends in one step."""
     import zlib
     from active_gym import AtariEnvArgs, AtariVecEnv
-    N, STEPS = 700, 14
     kw = dict(game="g", seed=11, obs_size=(84, 84), fov_size=(30, 30), fov_init_loc=(2, 3), sensory_action_mode="absolute",
-              resize_to_full=True, frame_source="native", frame_format=fmt, device="cuda:0", num_workers=4,
+              resize_to_full=True, frame_source="native", frame_format=fmt, device="cuda:0", num_workers=4 if N < 1000 else 12,
               scripted_actions=4, scripted_lives=2, scripted_p_life=250, scripted_p_over=60)      # ~ half of the envs end per step
     envs = []
     for loop in (True, False):
