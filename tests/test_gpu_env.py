@@ -735,6 +735,67 @@ def test_native_loop_binding_keeps_no_per_step_objects():
     env.close()
 
 
+@pytest.mark.parametrize("native_loop", [True, False])
+def test_two_envs_stepped_from_two_threads(native_loop):
+    """Two vector envs of one process stepped CONCURRENTLY from two Python threads (actor threads; ctypes releases the GIL inside the C
+    calls, the no-op callback takes it back): each must return exactly what it returns when it runs alone - nothing in the libraries
+    is shared between contexts but the device and its default stream."""
+    import threading
+    import zlib
+    from active_gym import AtariEnvArgs, AtariVecEnv
+    N, STEPS = 96, 40
+
+    def make(seed, kind, fmt):
+        import random
+        rnd = random.Random(seed)
+        return AtariVecEnv(AtariEnvArgs(game="g", seed=seed, obs_size=(84, 84), fov_size=(30, 30), fov_init_loc=(1, 2), sensory_action_mode="absolute",
+                                        resize_to_full=True, frame_source="native", frame_format=fmt, device="cuda:0", num_workers=3,
+                                        native_loop=native_loop, scripted_actions=4, scripted_lives=2, scripted_p_life=80, scripted_p_over=20),
+                           N, kind=kind, noop_fn=lambda r=rnd: r.randrange(30))
+
+    def run(env, seed, out, barrier=None):
+        try:
+            rng = np.random.default_rng(seed)
+            if barrier is not None:
+                barrier.wait()
+            o, _ = env.reset()
+            log = [zlib.crc32(o.cpu().numpy().tobytes())]
+            for _ in range(STEPS):
+                act = {"motor_action": rng.integers(0, 4, N), "sensory_action": rng.integers(-5, 60, (N, 2)).astype(np.int64)}
+                if env.kind == "flexible":
+                    act["sensory_action_type"] = rng.integers(0, 2, N)
+                o, r, d, _, info = env.step(act)
+                fin = 0
+                if d.any():
+                    for i in np.nonzero(d)[0]:
+                        fin = zlib.crc32(info["final_observation"][i].cpu().numpy().tobytes(), fin)
+                log.append((zlib.crc32(o.cpu().numpy().tobytes()), float(r.sum()), int(d.sum()), fin))
+            out.append(log)
+        except BaseException as e:  # noqa: BLE001 - reported by the main thread
+            out.append(e)
+
+    specs = [(3, "fixed", "rgb"), (4, "flexible", "gray")]
+    alone = []
+    for seed, kind, fmt in specs:
+        env = make(seed, kind, fmt)
+        run(env, seed, alone)
+        env.close()
+    envs = [make(*sp) for sp in specs]
+    outs = [[], []]
+    bar = threading.Barrier(2)
+    th = [threading.Thread(target=run, args=(envs[i], specs[i][0], outs[i], bar)) for i in range(2)]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join(300)
+    for e in envs:
+        e.close()
+    for i in range(2):
+        assert len(outs[i]) == 1 and not isinstance(outs[i][0], BaseException), outs[i]
+        assert outs[i][0] == alone[i], i
+    assert sum(x[2] for x in alone[0][1:]) > 50
+
+
 def test_c_loop_demo_matches_python_env(tmp_path):
     """examples/c_loop_demo.cpp drives the WHOLE vector step from plain C++ - libagx_runner.so's emulators (compact staging) into
     libagx.so's native step loop, autoreset inside, no Python, no torch; the same envs through AtariVecEnv must give the same
