@@ -739,7 +739,8 @@ def test_native_loop_binding_keeps_no_per_step_objects():
 def test_two_envs_stepped_from_two_threads(native_loop):
     """Two vector envs of one process stepped CONCURRENTLY from two Python threads (actor threads; ctypes releases the GIL inside the C
     calls, the no-op callback takes it back): each must return exactly what it returns when it runs alone - nothing in the libraries
-    is shared between contexts but the device and its default stream."""
+    is shared between contexts but the device.  Alone they run on the default stream, together each on a stream of its own thread:
+    everything an env enqueues (copy stream, event edges, kernels, torch's own work) must be ordered against the CALLER's stream."""
     import threading
     import zlib
     from active_gym import AtariEnvArgs, AtariVecEnv
@@ -754,6 +755,12 @@ def test_two_envs_stepped_from_two_threads(native_loop):
                            N, kind=kind, noop_fn=lambda r=rnd: r.randrange(30))
 
     def run(env, seed, out, barrier=None):
+        if barrier is None:
+            return body(env, seed, out, None)
+        with torch.cuda.stream(torch.cuda.Stream(device="cuda:0")):      # every actor thread on a stream of its own
+            body(env, seed, out, barrier)
+
+    def body(env, seed, out, barrier):
         try:
             rng = np.random.default_rng(seed)
             if barrier is not None:
