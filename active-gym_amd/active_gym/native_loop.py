@@ -87,6 +87,11 @@ class NativeStepLoop:
         rc = self._lib.agx_loop_create(pipe._ctx, C.byref(src), C.byref(cfg), C.byref(self._h))
         if rc:
             raise nat.AgxError(rc, (self._lib.agx_loop_last_error(None) or b"").decode())
+        # the loop holds the raw handles of both: whichever of the three is closed (or finalized) first closes the loop first
+        for owner in (pipe, runner):
+            if not hasattr(owner, "_dependents"):
+                owner._dependents = []
+            owner._dependents.append(self)
         self.n = pipe.num_envs
         self._motor = np.zeros(self.n, np.int32)
         self._motor_ptr = self._motor.ctypes.data
@@ -99,6 +104,9 @@ class NativeStepLoop:
             self._views = {}                                       # views of buffers that are about to be freed
             self._lib.agx_loop_destroy(self._h)
             self._h = _P()
+            for owner in (self.pipe, self.runner):
+                if self in getattr(owner, "_dependents", ()):
+                    owner._dependents.remove(self)
 
     def __del__(self):
         try:

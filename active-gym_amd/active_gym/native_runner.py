@@ -146,6 +146,8 @@ class NativeHostRunner:
             raise RuntimeError("libagx_runner: " + (self._lib.agxr_last_error(self._h) or b"").decode())
 
     def close(self):
+        for dep in list(getattr(self, "_dependents", ())):      # a native step loop holds this runner's raw handle as its host source
+            dep.close()
         if getattr(self, "_h", None) is not None and self._h.value:
             self._lib.agxr_destroy(self._h)
             self._h = _P()

@@ -97,6 +97,10 @@ class ObsPipeline:
 
     # ------------------------------------------------------------------ plumbing
     def close(self):
+        # a native step loop built on this context holds the raw handle: it goes first (also when the garbage collector runs the
+        # finalizers of an abandoned env in an order of its own)
+        for dep in list(getattr(self, "_dependents", ())):
+            dep.close()
         if getattr(self, "_ctx", None) is not None and self._ctx.value:
             self._lib.agx_destroy(self._ctx)
             self._ctx = C.c_void_p()

@@ -803,6 +803,53 @@ def test_two_envs_stepped_from_two_threads(native_loop):
     assert sum(x[2] for x in alone[0][1:]) > 50
 
 
+def test_native_loop_teardown_in_any_order():
+    """The step loop holds the raw handles of its context and of its runner.  A child process closes the three in every order,
+    abandons an env to the garbage collector (reference cycle through the no-op callback: finalizers in an order of the collector's
+    choosing) and leaves another alive at interpreter exit: no crash, and a closed env raises instead of stepping."""
+    import os
+    import subprocess
+    import sys
+    pkg = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "active-gym_amd")
+    code = r"""
+import gc, itertools, sys
+sys.path[:0] = [%r]
+import numpy as np, torch
+from active_gym import AtariEnvArgs, AtariVecEnv
+N = 24
+def make():
+    e = AtariVecEnv(AtariEnvArgs(game="g", seed=2, obs_size=(84, 84), fov_size=(30, 30), fov_init_loc=(0, 0), sensory_action_mode="absolute",
+                                 resize_to_full=True, frame_source="native", frame_format="gray", device="cuda:0", num_workers=2,
+                                 scripted_lives=2, scripted_p_life=100, scripted_p_over=30), N, kind="fixed")
+    assert e._loop is not None
+    e.reset()
+    for _ in range(5):
+        e.step({"motor_action": np.zeros(N, np.int64), "sensory_action": np.full((N, 2), 20, np.int64)})
+    return e
+for order in itertools.permutations(("loop", "pipe", "runner")):
+    e = make()
+    parts = {"loop": e._loop, "pipe": e.pipe, "runner": e.runner}
+    for name in order:
+        parts[name].close()
+    e.close()
+    try:
+        e.step({"motor_action": np.zeros(N, np.int64), "sensory_action": np.full((N, 2), 20, np.int64)})
+        raise SystemExit("a closed env stepped")
+    except SystemExit:
+        raise
+    except Exception:
+        pass
+for _ in range(3):
+    e = make()
+    del e
+    gc.collect()
+keep = make()
+print("teardown ok", flush=True)
+""" % pkg
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and "teardown ok" in r.stdout, (r.returncode, r.stdout[-500:], r.stderr[-2000:])
+
+
 def test_c_loop_demo_matches_python_env(tmp_path):
     """examples/c_loop_demo.cpp drives the WHOLE vector step from plain C++ - libagx_runner.so's emulators (compact staging) into
     libagx.so's native step loop, autoreset inside, no Python, no torch; the same envs through AtariVecEnv must give the same
