@@ -803,6 +803,62 @@ def test_two_envs_stepped_from_two_threads(native_loop):
     assert sum(x[2] for x in alone[0][1:]) > 50
 
 
+def test_loop_abi_error_paths():
+    """include/agx_loop.h: every misuse is an error code and a message, never a crash - null arguments, a config of the wrong size,
+    a host source without its callbacks, a fovea context stepped without its fov_loc buffer, env indices out of range, a callback
+    that fails (the step reports it and the loop stays usable)."""
+    import ctypes as C
+    from active_gym import AtariEnvArgs, AtariVecEnv, _native as nat
+    from active_gym import native_loop as NL
+    N = 12
+    env = AtariVecEnv(AtariEnvArgs(game="g", seed=2, obs_size=(84, 84), fov_size=(30, 30), fov_init_loc=(0, 0), sensory_action_mode="absolute",
+                                   resize_to_full=True, frame_source="native", frame_format="gray", device="cuda:0", num_workers=2,
+                                   scripted_lives=2, scripted_p_life=100, scripted_p_over=30), N, kind="fixed")
+    lp = env._loop
+    lib = lp._lib
+    P = C.c_void_p
+    src = NL.AgxHostSource()
+    src.self = env.runner._h
+    src.step = C.cast(env.runner._lib.agxr_step, P)
+    src.reset_packed = C.cast(env.runner._lib.agxr_reset_packed, P)
+    good = NL.AgxLoopConfig(C.sizeof(NL.AgxLoopConfig), 1, 1, 1)
+    out = P()
+    assert lib.agx_loop_create(None, C.byref(src), C.byref(good), C.byref(out)) == nat.E_INVALID and not out.value
+    assert lib.agx_loop_create(env.pipe._ctx, None, C.byref(good), C.byref(out)) == nat.E_INVALID
+    bad = NL.AgxLoopConfig(8, 1, 1, 1)
+    assert lib.agx_loop_create(env.pipe._ctx, C.byref(src), C.byref(bad), C.byref(out)) == nat.E_INVALID and not out.value
+    assert b"struct_size" in lib.agx_loop_last_error(None)
+    nosrc = NL.AgxHostSource()
+    assert lib.agx_loop_create(env.pipe._ctx, C.byref(nosrc), C.byref(good), C.byref(out)) == nat.E_INVALID
+    assert b"step and reset_packed" in lib.agx_loop_last_error(None)
+    env.reset()
+    motor = np.zeros(N, np.int32)
+    res = NL.AgxLoopResult()
+    obs, loc = env._obs, env._loc
+    st = lp._stream()
+    assert lib.agx_loop_step(None, motor.ctypes.data, None, 0, None, P(obs.data_ptr()), P(loc.data_ptr()), None, C.byref(res), st) == nat.E_INVALID
+    assert lib.agx_loop_step(lp._h, None, None, 0, None, P(obs.data_ptr()), P(loc.data_ptr()), None, C.byref(res), st) == nat.E_INVALID
+    assert lib.agx_loop_step(lp._h, motor.ctypes.data, None, 0, None, None, P(loc.data_ptr()), None, C.byref(res), st) == nat.E_INVALID
+    assert lib.agx_loop_step(lp._h, motor.ctypes.data, None, 0, None, P(obs.data_ptr()), None, None, C.byref(res), st) == nat.E_INVALID
+    assert b"d_fov_loc" in lib.agx_loop_last_error(lp._h)
+    idx = np.array([0, N], np.int32)
+    assert lib.agx_loop_reset_envs(lp._h, idx.ctypes.data, 2, None, P(obs.data_ptr()), P(loc.data_ptr()), None, st) == nat.E_INVALID
+    assert b"out of range" in lib.agx_loop_last_error(lp._h)
+    assert lib.agx_loop_reset_envs(lp._h, idx.ctypes.data, 0, None, P(obs.data_ptr()), P(loc.data_ptr()), None, st) == nat.OK
+    assert lib.agx_loop_reset(lp._h, None, None, None, None, st) == nat.E_INVALID
+    # a motor action outside the action set: the runner's step callback refuses it, the loop reports the host source's reason
+    motor[3] = 99
+    with pytest.raises(nat.AgxError, match="host source"):
+        lp.step(motor, None, 0, None, obs, loc, None)
+    motor[3] = 0
+    act = {"motor_action": np.zeros(N, np.int64), "sensory_action": np.full((N, 2), 20, np.int64)}
+    for _ in range(10):                                              # ... and keeps working
+        o, r, d, _, info = env.step(act)
+    assert np.isfinite(o.cpu().numpy()).all()
+    assert lib.agx_loop_destroy(None) == nat.OK
+    env.close()
+
+
 def test_native_loop_teardown_in_any_order():
     """The step loop holds the raw handles of its context and of its runner.  A child process closes the three in every order,
     abandons an env to the garbage collector (reference cycle through the no-op callback: finalizers in an order of the collector's
