@@ -285,8 +285,9 @@ def run_e2e(dev, n, hc, rank=0):
     import torch
     from active_gym import AtariEnvArgs, AtariVecEnv
     # emulator threads: twice the cores this job may use (affinity and cgroup quota), at most 64.  The scripted emulator's threads
-    # mostly wait on screen writes to pinned memory; measured on a 16-core quota (tools/e2e_workers.py, N = 1024): 16 threads
-    # 0.228 M / 0.644 M env steps/s (RGB / gray screens), 32 threads 0.269 M / 0.770 M, 64 threads 0.267 M / 0.779 M
+    # mostly wait on screen writes to pinned memory; measured on a 16-core quota (tools/e2e_phases.py, N = 1024, profiles/
+    # r04_e2e_phases_*.txt): 12 / 16 / 24 / 32 threads 0.34 / 0.34 / 0.33 / 0.33 M env steps/s with RGB screens (the PCIe copy from 12
+    # threads up), 0.92 / 0.96 / 1.0 / 1.0 M with gray screens; 64 pinned threads under that quota are throttled to 0.24-0.28 M
     lws = max(1, int(os.environ.get("LOCAL_WORLD_SIZE", "1") or 1))            # one process per GPU shares the host with its siblings
     workers = max(1, min(64, 2 * hc["usable"] // lws))
     out = {"envs": n, "runner": "libagx_runner.so (C++ threads, scripted emulator)", "workers": workers, "h2d_chunk_envs": 0,
