@@ -95,6 +95,7 @@ struct ScriptedEmu final : Emulator {
         return (uint32_t)((seed * 1000003ull + (uint64_t)episode * 7919ull + (uint64_t)frame * 31ull) & 0xFFFFu);
     }
     static void rgb_row(uint32_t K, int y, uint8_t *row) {
+        if (have_vbmi()) return rgb_row_vbmi(K, y, row);
         for (int x = 0; x < kW; ++x) {
             const uint32_t base = (uint32_t)(y * 7 + x * 13) + K * 3u + (uint32_t)((y * x) >> 4);
             uint8_t *p = row + (size_t)x * 3;
@@ -106,10 +107,12 @@ struct ScriptedEmu final : Emulator {
     void screen_rgb(uint8_t *out) override {
         const uint32_t K = screen_key();
         for (int y = 0; y < kH; ++y) rgb_row(K, y, out + (size_t)y * kW * 3);
+        if (nt_stores()) _mm_sfence();
     }
     void screen_rgb_rows(uint8_t *out, const int32_t *rows, int n) override {      // only the wanted rows are generated at all
         const uint32_t K = screen_key();
         for (int k = 0; k < n; ++k) rgb_row(K, rows[k], out + (size_t)k * kW * 3);
+        if (nt_stores()) _mm_sfence();
     }
     static void gray_lut(uint32_t K, uint8_t *lut) {
         // r, g, b are functions of (base & 0xFF) for a given K: one 256-entry table per screen, like ALE's palette
@@ -133,13 +136,23 @@ struct ScriptedEmu final : Emulator {
             idx[x] = (uint8_t)((uint32_t)(y * 7 + x * 13) + K * 3u + (uint32_t)((y * x) >> 4));
         for (int x = 0; x < kW; ++x) row[x] = lut[idx[x]];
     }
-    // The same row where the CPU has AVX-512 VBMI (every MI355X host: EPYC Zen 4 / 5): the index in 16-bit lanes (y x < 2^16, and
-    // only the low byte of the sum is kept, so the wrap-around of the other terms does not matter), truncated to bytes, and the
-    // 256-entry table walked 64 entries at a time - two vpermi2b over the table's halves, selected by the index's top bit.  The
-    // scalar table walk was 85 % of a gray screen (13 of 15 us); this is what ALE does per screen too (palette -> gray), so a
-    // stand-in that spends its time there is not unfair to ALE, only slower than it has to be.
-    __attribute__((target("avx512f,avx512bw,avx512vl,avx512vbmi"))) static void gray_row_vbmi(uint32_t K, const uint8_t *lut, int y,
-                                                                                               uint8_t *row) {
+    // Staging rows are written once and read next by the DMA engine: the vector paths below use streaming stores, which keep
+    // 55-165 MB per step out of the cores' caches (gray e2e step 1.02 against 1.03-1.10 ms, tighter medians: profiles/
+    // r04_runner_nt_stores_ab.txt).  AGXR_NO_NT_STORES=1 restores ordinary stores.
+    static bool nt_stores() {
+        static const bool v = std::getenv("AGXR_NO_NT_STORES") == nullptr;
+        return v;
+    }
+    static bool have_vbmi() {
+        static const bool v = !std::getenv("AGXR_NO_VBMI") && __builtin_cpu_supports("avx512vbmi") && __builtin_cpu_supports("avx512bw") &&
+                              __builtin_cpu_supports("avx512vl");
+        return v;
+    }
+#define AGXR_VBMI __attribute__((target("avx512f,avx512bw,avx512vl,avx512vbmi")))
+    // The rows where the CPU has AVX-512 VBMI (every MI355X host: EPYC Zen 4 / 5).  The palette index of the 160 pixels of a row in
+    // 16-bit lanes (y x < 2^16, and only the low byte of the sum is kept, so the wrap-around of the other terms does not matter),
+    // truncated to bytes: idx[0..63], idx[64..127], idx[128..159] (+ 32 zero bytes).
+    AGXR_VBMI static void row_index_vbmi(uint32_t K, int y, __m512i out[3]) {
         alignas(64) static const uint16_t X[kW] = {
 #define R8(b) (b), (b) + 1, (b) + 2, (b) + 3, (b) + 4, (b) + 5, (b) + 6, (b) + 7
 #define R32(b) R8(b), R8((b) + 8), R8((b) + 16), R8((b) + 24)
@@ -147,8 +160,6 @@ struct ScriptedEmu final : Emulator {
 #undef R32
 #undef R8
         };
-        const __m512i t0 = _mm512_loadu_si512(lut), t1 = _mm512_loadu_si512(lut + 64), t2 = _mm512_loadu_si512(lut + 128),
-                      t3 = _mm512_loadu_si512(lut + 192);
         const __m512i vy = _mm512_set1_epi16((short)y), vb = _mm512_set1_epi16((short)((uint32_t)(y * 7) + K * 3u));
         const __m512i v13 = _mm512_set1_epi16(13);
         __m256i b[5];
@@ -158,22 +169,58 @@ struct ScriptedEmu final : Emulator {
                                                _mm512_srli_epi16(_mm512_mullo_epi16(vy, xs), 4));
             b[j] = _mm512_cvtepi16_epi8(v);
         }
-        // (a lambda would not inherit the target attribute)
-#define AGXR_WALK(idx) \
-    _mm512_mask_blend_epi8(_mm512_movepi8_mask(idx), _mm512_permutex2var_epi8(t0, (idx), t1), _mm512_permutex2var_epi8(t2, (idx), t3))
-        const __m512i i0 = _mm512_inserti64x4(_mm512_castsi256_si512(b[0]), b[1], 1);
-        const __m512i i1 = _mm512_inserti64x4(_mm512_castsi256_si512(b[2]), b[3], 1);
-        const __m512i i2 = _mm512_castsi256_si512(b[4]);
-        _mm512_storeu_si512(row, AGXR_WALK(i0));
-        _mm512_storeu_si512(row + 64, AGXR_WALK(i1));
-        _mm256_storeu_si256(reinterpret_cast<__m256i *>(row + 128), _mm512_castsi512_si256(AGXR_WALK(i2)));
-#undef AGXR_WALK
+        out[0] = _mm512_inserti64x4(_mm512_castsi256_si512(b[0]), b[1], 1);
+        out[1] = _mm512_inserti64x4(_mm512_castsi256_si512(b[2]), b[3], 1);
+        out[2] = _mm512_zextsi256_si512(b[4]);
     }
-    static bool have_vbmi() {
-        static const bool v = !std::getenv("AGXR_NO_VBMI") && __builtin_cpu_supports("avx512vbmi") && __builtin_cpu_supports("avx512bw") &&
-                              __builtin_cpu_supports("avx512vl");
-        return v;
+    // n32 32-byte pieces of v[] to dst (32-byte aligned for the streaming form; rows are 160 / 480 bytes from a page-aligned base)
+    AGXR_VBMI static void store_pieces(uint8_t *dst, const __m512i *v, int n32) {
+        if (nt_stores() && (reinterpret_cast<uintptr_t>(dst) & 31u) == 0) {
+            __m256i *d = reinterpret_cast<__m256i *>(dst);
+            for (int k = 0; k < n32; ++k)
+                _mm256_stream_si256(d + k, (k & 1) ? _mm512_extracti64x4_epi64(v[k >> 1], 1) : _mm512_castsi512_si256(v[k >> 1]));
+        } else {
+            for (int k = 0; k < n32; ++k)
+                _mm256_storeu_si256(reinterpret_cast<__m256i *>(dst) + k,
+                                    (k & 1) ? _mm512_extracti64x4_epi64(v[k >> 1], 1) : _mm512_castsi512_si256(v[k >> 1]));
+        }
     }
+    // gray: the 256-entry table walked 64 entries at a time - two vpermi2b over the table's halves, selected by the index's top bit.
+    // The scalar table walk was 85 % of a gray screen (13 of 15 us); it is what ALE does per screen too (palette -> gray), so a
+    // stand-in that spends its time there is not unfair to ALE, only slower than it has to be.
+    AGXR_VBMI static void gray_row_vbmi(uint32_t K, const uint8_t *lut, int y, uint8_t *row) {
+        const __m512i t0 = _mm512_loadu_si512(lut), t1 = _mm512_loadu_si512(lut + 64), t2 = _mm512_loadu_si512(lut + 128),
+                      t3 = _mm512_loadu_si512(lut + 192);
+        __m512i idx[3], o[3];
+        row_index_vbmi(K, y, idx);
+        for (int j = 0; j < 3; ++j)
+            o[j] = _mm512_mask_blend_epi8(_mm512_movepi8_mask(idx[j]), _mm512_permutex2var_epi8(t0, idx[j], t1),
+                                          _mm512_permutex2var_epi8(t2, idx[j], t3));
+        store_pieces(row, o, 5);
+    }
+    // RGB: byte t of the row is idx[t / 3] + {0, 29, 58 + (K >> 3)}[t % 3] (mod 256).  192 output bytes per 64 indices, so output
+    // vector j takes its indices from idx[j / 3] through one of three fixed vpermb patterns, and its offsets from one of three
+    // phase patterns (64 = 1 mod 3: the phase moves by one per vector).
+    AGXR_VBMI static void rgb_row_vbmi(uint32_t K, int y, uint8_t *row) {
+        alignas(64) static uint8_t P[3][64], PH[3][64];
+        static const bool init = [] {
+            for (int m = 0; m < 3; ++m)
+                for (int t = 0; t < 64; ++t) P[m][t] = (uint8_t)((64 * m + t) / 3), PH[m][t] = (uint8_t)((64 * m + t) % 3);
+            return true;
+        }();
+        (void)init;
+        alignas(64) uint8_t off[64] = {0, 29, (uint8_t)(58u + (K >> 3))};
+        const __m512i voff = _mm512_load_si512(off);
+        __m512i idx[3], o[8];
+        row_index_vbmi(K, y, idx);
+        for (int j = 0; j < 8; ++j) {
+            const int m = j % 3;
+            const __m512i src = _mm512_permutexvar_epi8(_mm512_load_si512(P[m]), idx[j / 3]);
+            o[j] = _mm512_add_epi8(src, _mm512_permutexvar_epi8(_mm512_load_si512(PH[m]), voff));
+        }
+        store_pieces(row, o, 15);
+    }
+#undef AGXR_VBMI
     static void gray_row(uint32_t K, const uint8_t *lut, int y, uint8_t *row) {
         if (have_vbmi()) gray_row_vbmi(K, lut, y, row);
         else gray_row_scalar(K, lut, y, row);
@@ -183,12 +230,14 @@ struct ScriptedEmu final : Emulator {
         uint8_t lut[256];
         gray_lut(K, lut);
         for (int y = 0; y < kH; ++y) gray_row(K, lut, y, out + (size_t)y * kW);
+        if (nt_stores()) _mm_sfence();
     }
     void screen_gray_rows(uint8_t *out, const int32_t *rows, int n) override {
         const uint32_t K = screen_key();
         uint8_t lut[256];
         gray_lut(K, lut);
         for (int k = 0; k < n; ++k) gray_row(K, lut, rows[k], out + (size_t)k * kW);
+        if (nt_stores()) _mm_sfence();
     }
     std::vector<int> minimal_actions() override {
         std::vector<int> v(n_actions);

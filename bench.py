@@ -284,12 +284,13 @@ def run_e2e(dev, n, hc, rank=0):
     import numpy as np
     import torch
     from active_gym import AtariEnvArgs, AtariVecEnv
-    # emulator threads: twice the cores this job may use (affinity and cgroup quota), at most 64.  The scripted emulator's threads
-    # mostly wait on screen writes to pinned memory; measured on a 16-core quota (tools/e2e_phases.py, N = 1024, profiles/
-    # r04_e2e_phases_*.txt): 12 / 16 / 24 / 32 threads 0.34 / 0.34 / 0.33 / 0.33 M env steps/s with RGB screens (the PCIe copy from 12
-    # threads up), 0.92 / 0.96 / 1.0 / 1.0 M with gray screens; 64 pinned threads under that quota are throttled to 0.24-0.28 M
+    # emulator threads: the product's default - the cores this job may use (affinity and cgroup quota) divided between the ranks of
+    # the host, one pinned thread per CPU.  Measured on a 16-core quota (tools/e2e_phases.py, N = 1024, profiles/r04_e2e_phases_*.txt):
+    # 12 / 16 threads 0.338 / 0.338 M env steps/s median with RGB screens, 0.98 / 0.98 M with gray screens (the PCIe copy either way);
+    # 24 / 32 threads (two per CPU) reach the same best step but fall into 3-6 ms medians every few runs.  (Rounds 1-3 ran 2 x the
+    # cores: the scripted emulator was four times as expensive then and its threads mostly waited on their screen writes.)
     lws = max(1, int(os.environ.get("LOCAL_WORLD_SIZE", "1") or 1))            # one process per GPU shares the host with its siblings
-    workers = max(1, min(64, 2 * hc["usable"] // lws))
+    workers = max(1, min(64, hc["usable"] // lws))
     out = {"envs": n, "runner": "libagx_runner.so (C++ threads, scripted emulator)", "workers": workers, "h2d_chunk_envs": 0,
            "local_world_size": lws,
            "overlap": "double-buffered pinned staging: the emulators of step t+1 run under the H2D copy and kernels of step t",
