@@ -49,9 +49,13 @@ def parse():
     ap.add_argument("--out", default="full", choices=("full", "packed"),
                     help="flexible kind: full = resize_to_full (the config-4 workload); packed = the ragged raw-crop sub-run "
                          "(agx_fovea_flexible_packed: [fs, rh, rw] crops packed back to back + offsets)")
-    ap.add_argument("--preroll", type=int, default=200,
+    ap.add_argument("--preroll", type=int, default=1000,
                     help="untimed steps run BEFORE the warmup so that a short run (the driver's --steps 20) is not timed on the "
-                         "first millisecond of an idle device (clock ramp); not part of `warmup` or `steps`")
+                         "first milliseconds of an idle device (clock ramp); not part of `warmup` or `steps`")
+    ap.add_argument("--rehearsals", type=int, default=4,
+                    help="untimed dress rehearsals of the timed region (synchronize, `steps` steps, synchronize) between the pre-roll and "
+                         "the warmup: the first synchronize -> launch -> synchronize cycle of a process runs 1-2.5 us per step slower "
+                         "than the following ones (profiles/r04_region_sequence.txt)")
     ap.add_argument("--samples", type=int, default=24,
                     help="launch pairs carrying their own HIP events in the sampling pass that FOLLOWS the timed region")
     ap.add_argument("--obs-pool", type=int, default=3,
@@ -532,9 +536,14 @@ def main():
     # untimed pre-roll: the device leaves its idle clocks before anything is timed (a 20-step run is 1.3 ms long)
     for k in range(args.preroll):
         step(k)
+    K = args.steps
+    for _ in range(max(0, args.rehearsals)):
+        torch.cuda.synchronize(dev)
+        for k in range(K):
+            step(k)
+        torch.cuda.synchronize(dev)
     for k in range(args.warmup):
         step(k)
-    K = args.steps
     barrier(dist, local_rank)
     torch.cuda.synchronize(dev)
     issued["events"] = 0
@@ -654,7 +663,7 @@ def main():
         out = {
             "metric": "env steps/sec at N=1024 AtariFixedFovealEnv; 1/2/4/8-GPU scaling",
             "value": total_envs * K / elapsed, "unit": "env steps/s", "n_gpus": world, "steps": K, "warmup": args.warmup,
-            "preroll": args.preroll, "events_in_timed_region": events_in_timed_region, "host_wait": host_wait,
+            "preroll": args.preroll, "rehearsals": args.rehearsals, "events_in_timed_region": events_in_timed_region, "host_wait": host_wait,
             "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "u8 ingest / f32 resize", "data": "synthetic",
             "config": {"workload": workload_name(args, n, packed_mode, gray, use_compact),

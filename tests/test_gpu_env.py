@@ -449,7 +449,7 @@ def test_bench_contract_json():
     assert abs(d["value"] - 64 * 8 / (d["ms_per_step"] * 8e-3)) / d["value"] < 1e-6
     # the timed region is K plain steps: no HIP event is created for, handed to or recorded around any of its launches
     # (the per-kernel durations behind `roofline` come from a sampling pass that follows it)
-    assert d["events_in_timed_region"] == 0 and d["preroll"] >= 0
+    assert d["events_in_timed_region"] == 0 and d["preroll"] >= 0 and d["rehearsals"] >= 0
     assert r["launches_timed"] >= 16 and "sampling pass" in r["timing"]
     # round 4: the fovea kernel against HBM (its output rotating through more buffers than the Infinity Cache holds), the same step on
     # the runner's compact staging layout, and the e2e leg's placement / staging facts
