@@ -571,6 +571,9 @@ def main():
             for x in e:
                 x.record()
         torch.cuda.synchronize(dev)
+        for j in range(100):           # run-up: the synchronisation above let the device idle (see --rehearsals)
+            step(k0 + j)
+        k0 += 100
         for j in range(S_ * M):
             step(k0 + j, ev_[j // M] if j % M == M - 1 else None)
         torch.cuda.synchronize(dev)
