@@ -533,6 +533,9 @@ def main():
         if e is not None:
             e[2].record()
 
+    # the first collective of a process group builds its communicator (RCCL: hundreds of milliseconds): here, not in the barrier
+    # in front of the timed region, where it would leave the device idle for that long right before t0
+    barrier(dist, local_rank)
     # untimed pre-roll: the device leaves its idle clocks before anything is timed (a 20-step run is 1.3 ms long)
     for k in range(args.preroll):
         step(k)
