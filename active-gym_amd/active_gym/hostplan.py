@@ -162,6 +162,23 @@ def plan(topo: Dict, local_rank: int, local_world_size: int, gpu_nodes: Optional
     return {"workers": n_workers, "cpus": cpus, "domain": domain, "numa_node": node, "usable": usable, "per_rank": per_rank}
 
 
+def infer_peer_nodes(seen: Sequence[Optional[int]], local_rank: int, host_nodes: Sequence[int]) -> List[Optional[int]]:
+    """NUMA nodes of all ranks' GPUs from what THIS process can see.  A launcher that masks the devices (one visible GPU per
+    process) leaves the peers' entries None: if the ranks are spread over the host's nodes in blocks (ranks 0..3 on node 0, 4..7 on
+    node 1 - the usual order) and that guess agrees with this rank's own node, the unknown peers are taken from it, so that a rank
+    shares its node's CPUs with the ranks that are really there; otherwise an unknown peer is taken to sit beside this rank
+    (disjoint CPU sets either way, at worst smaller than they could be)."""
+    lws = len(seen)
+    own = seen[local_rank] if 0 <= local_rank < lws else None
+    guess = None
+    if host_nodes and lws % len(host_nodes) == 0:
+        per = lws // len(host_nodes)
+        guess = [host_nodes[q // per] for q in range(lws)]
+        if own is None or guess[local_rank] != own or any(v is not None and v != g for v, g in zip(seen, guess)):
+            guess = None
+    return [v if v is not None else (guess[q] if guess is not None else own) for q, v in enumerate(seen)]
+
+
 def plan_for_process(device_index: int, workers: Optional[int] = None, topo: Optional[Dict] = None) -> Dict:
     """The plan of THIS process: LOCAL_RANK / LOCAL_WORLD_SIZE from the launcher's environment (one process per GPU), the
     GPUs' NUMA nodes from sysfs.  AGX_NO_PIN=1 (or an unreadable topology) yields an unpinned plan (cpus = [])."""
@@ -171,8 +188,7 @@ def plan_for_process(device_index: int, workers: Optional[int] = None, topo: Opt
     # rank r drives device r of the node, except in a one-process job, which may sit on any device (and in rehearsals that let
     # several ranks share one device: a rank whose device ordinal does not exist is taken to sit beside this one)
     own = gpu_numa_node(device_index)
-    nodes = [own if (lws == 1 or q == lr) else gpu_numa_node(q) for q in range(lws)]
-    nodes = [own if v is None else v for v in nodes]
+    nodes = infer_peer_nodes([own if (lws == 1 or q == lr) else gpu_numa_node(q) for q in range(lws)], lr, sorted(topo.get("nodes", {})))
     p = plan(topo, lr, lws, nodes, workers)
     if os.environ.get("AGX_NO_PIN") == "1":
         p["cpus"] = []

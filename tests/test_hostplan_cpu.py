@@ -77,6 +77,30 @@ def test_override_unknown_node_and_restricted_affinity():
     assert [plan(tiny, r, 4, [0] * 4)["cpus"] for r in range(4)] == [[0], [0], [1], [1]]
 
 
+def test_peers_behind_a_device_mask_are_placed_by_rank_blocks():
+    """One visible GPU per process (a launcher that masks devices): the peers' NUMA nodes are unknown.  With ranks in node blocks
+    the guess gives every rank its true share; where the guess contradicts what is known, unknown peers sit beside this rank."""
+    from active_gym.hostplan import infer_peer_nodes, plan
+    topo = _mi355x_node()
+    truth = [0, 0, 0, 0, 1, 1, 1, 1]
+    seen_total = set()
+    for r in range(8):
+        seen = [truth[q] if q == r else None for q in range(8)]
+        nodes = infer_peer_nodes(seen, r, [0, 1])
+        assert nodes == truth
+        p = plan(topo, r, 8, nodes)
+        assert len(p["domain"]) == 32 and not (set(p["domain"]) & seen_total)
+        seen_total |= set(p["domain"])
+    # own node contradicts the block guess (rank 1 on node 1): no guess, peers beside this rank
+    assert infer_peer_nodes([None, 1, None, None], 1, [0, 1]) == [1, 1, 1, 1]
+    # a visible peer contradicts it
+    assert infer_peer_nodes([0, 1, None, None], 0, [0, 1]) == [0, 1, 0, 0]
+    # nothing known at all, one rank, more nodes than ranks
+    assert infer_peer_nodes([None, None], 0, [0, 1]) == [None, None]
+    assert infer_peer_nodes([None], 0, [0, 1]) == [None]
+    assert infer_peer_nodes([0, None, None], 0, [0, 1]) == [0, 0, 0]
+
+
 def test_read_topology_and_bound_to_on_this_host():
     from active_gym import hostplan
     topo = hostplan.read_topology(refresh=True)
