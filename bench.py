@@ -708,9 +708,12 @@ def main():
             else:
                 out["e2e_per_rank"] = e2e_all
                 ok = [x for x in e2e_all if isinstance(x, dict) and "error" not in x]
-                out["e2e_aggregate"] = {fmt: {"env_steps_per_s_median": sum(x[fmt]["env_steps_per_s_median"] for x in ok),
-                                              "env_steps_per_s_best": sum(x[fmt]["env_steps_per_s"] for x in ok)} for fmt in ("rgb", "gray")}
-                out["e2e_aggregate"]["ranks"] = len(ok)
+                try:
+                    out["e2e_aggregate"] = {fmt: {"env_steps_per_s_median": sum(x[fmt]["env_steps_per_s_median"] for x in ok),
+                                                  "env_steps_per_s_best": sum(x[fmt]["env_steps_per_s"] for x in ok)} for fmt in ("rgb", "gray")}
+                    out["e2e_aggregate"]["ranks"] = len(ok)
+                except (KeyError, TypeError) as ex:      # a rank's leg came back incomplete: the line still goes out
+                    out["e2e_aggregate"] = {"error": repr(ex), "ranks": len(ok)}
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args.cpu_seconds, 1234)
         print(json.dumps(out), flush=True)
