@@ -19,6 +19,7 @@ FOV_LOC, FOV_RES = 0, 1
 CMD_CLEAR, CMD_SKIP = 0x04, 0x08
 K_INGEST, K_FOVEA, K_FULL, K_INGEST_RGB, K_INGEST_GRAY_RAW = 1, 2, 3, 4, 5
 GRAY_CV15, GRAY_CV14 = 0, 1
+SCREENS_GRAY, SCREENS_COMPACT = 1, 2          # agx_step_flexible_packed: screen layout bits
 
 RAW_H, RAW_W = 210, 160
 
@@ -63,6 +64,7 @@ SIGNATURES = {
     "agx_fovea_peripheral": (C.c_int, [_P, _P, C.c_int, _P, _P, _P, _P]),
     "agx_fovea_flexible": (C.c_int, [_P, _P, C.c_int, _P, _P, _P, _P, _P, _P]),
     "agx_fovea_flexible_packed": (C.c_int, [_P, _P, C.c_int, _P, _P, C.c_int64, _P, _P, _P, _P]),
+    "agx_step_flexible_packed": (C.c_int, [_P, _P, C.c_int, _P, _P, C.c_int, _P, _P, C.c_int64, _P, _P, _P, _P]),
 }
 
 _lib = None
@@ -86,7 +88,12 @@ def lib():
             "active_gym has no CPU fallback for the observation path.")
     handle = C.CDLL(path)
     for name, (res, args) in SIGNATURES.items():
-        fn = getattr(handle, name)           # AttributeError if the .so does not export it
+        try:
+            fn = getattr(handle, name)       # AttributeError if the .so does not export it
+        except AttributeError:
+            if os.environ.get("AGX_LIB") and name == "agx_step_flexible_packed":
+                continue                     # an older diagnostic build selected by hand (tools/canary_probe.py's r3bug library)
+            raise
         fn.restype = res
         fn.argtypes = args
     v = handle.agx_abi_version()

@@ -270,6 +270,53 @@ class ObsPipeline:
                                                       pr, self._stream()), self._ctx)
         return packed, offsets, loc_out, res_out
 
+    def step_flexible_packed(self, screens: torch.Tensor, cmd: torch.Tensor, action: Optional[torch.Tensor] = None,
+                             action_type: Optional[torch.Tensor] = None, packed: Optional[torch.Tensor] = None,
+                             offsets: Optional[torch.Tensor] = None, loc_out: Optional[torch.Tensor] = None,
+                             res_out: Optional[torch.Tensor] = None):
+        """One whole step of a flexible raw-crop pipeline with packed ragged observations - ``ingest*(screens, cmd)`` followed by
+        :meth:`fovea_packed` - in one ABI call and two launches (agx_step_flexible_packed: the state update + scan ride in the
+        ingest launch).  `screens`: u8 [N,2,210,160,3] | [N,2,210,160] (ALE grayscale) | [N,2,R,160,3] | [N,2,R,160] with R =
+        len(source_rows()) (compact).  Same results as the two calls; returns what :meth:`fovea_packed` returns."""
+        if self.kind != "flexible" or self.out_mode != nat.OUT_RAW:
+            raise RuntimeError("step_flexible_packed needs kind='flexible' in raw-crop mode (no mask_out, no resize_to_full)")
+        N = self.num_envs
+        if not hasattr(self, "_n_src"):
+            self._n_src = len(self.source_rows())
+        if not isinstance(screens, torch.Tensor) or screens.dim() not in (4, 5):
+            raise ValueError("screens must be a u8 tensor [N,2,rows,160,3] (RGB) or [N,2,rows,160] (gray)")
+        gray = screens.dim() == 4
+        rows = int(screens.shape[2])
+        if rows not in (nat.RAW_H, self._n_src):
+            raise ValueError(f"screens have {rows} rows; whole screens have {nat.RAW_H}, compact ones {self._n_src}")
+        compact = rows != nat.RAW_H
+        ps = self._chk(screens, (N, 2, rows, nat.RAW_W) + (() if gray else (3,)), torch.uint8, "screens")
+        pc = self._chk(cmd, (N,), torch.uint8, "cmd")
+        pa, dt = None, 0
+        if action is not None:
+            if action.dtype not in _DT:
+                raise TypeError(f"sensory action dtype {action.dtype} not supported (f32/f64/i32/i64)")
+            pa = self._chk(action, (N, 2), None, "action")
+            dt = _DT[action.dtype]
+        pt = self._chk(action_type, (N,), torch.int32, "action_type") if action_type is not None else None
+        if packed is None:
+            packed = torch.empty((N * self.frame_stack * self.obs_size[0] * self.obs_size[1],), dtype=torch.float32, device=self.device)
+        if packed.dtype != torch.float32 or packed.device != self.device or packed.dim() != 1 or not packed.is_contiguous():
+            raise ValueError("packed must be a contiguous 1-D float32 tensor on the pipeline's device")
+        if offsets is None:
+            offsets = torch.empty((N + 1,), dtype=torch.int64, device=self.device)
+        pof = self._chk(offsets, (N + 1,), torch.int64, "offsets")
+        if loc_out is None:
+            loc_out = torch.empty((N, 2), dtype=torch.int32, device=self.device)
+        if res_out is None:
+            res_out = torch.empty((N, 2), dtype=torch.int32, device=self.device)
+        pl = self._chk(loc_out, (N, 2), torch.int32, "loc_out")
+        pr = self._chk(res_out, (N, 2), torch.int32, "res_out")
+        layout = (nat.SCREENS_GRAY if gray else 0) | (nat.SCREENS_COMPACT if compact else 0)
+        nat.check(self._lib.agx_step_flexible_packed(self._ctx, ps, layout, pc, pa, dt, pt, C.c_void_p(packed.data_ptr()), packed.numel(),
+                                                     pof, pl, pr, self._stream()), self._ctx)
+        return packed, offsets, loc_out, res_out
+
     def fovea_reset(self, mask: Optional[torch.Tensor] = None):
         pm = self._chk(mask, (self.num_envs,), torch.uint8, "mask") if mask is not None else None
         nat.check(self._lib.agx_fovea_reset(self._ctx, pm, self._stream()), self._ctx)

@@ -558,8 +558,14 @@ class AtariVecEnv:
         else:
             reward, done, cmd, raw = self.runner.step(motor)
             self._upload(cmd)
-        self._ingest()
-        obs = self._observe(sens, stype)
+        if self._ragged_packed and sens is not None:
+            # packed ragged observations: ingest + state / scan + crops as one ABI call, two launches (agx_step_flexible_packed)
+            self.pipe.step_flexible_packed(self._d_frames, self._d_cmd, sens, action_type=stype, packed=self._packed,
+                                           offsets=self._poff, loc_out=self._loc, res_out=self._res)
+            obs = self._obs
+        else:
+            self._ingest()
+            obs = self._observe(sens, stype)
         self.ep_len += 1
         self.cumulative_reward += raw                   # unclipped, fov_env.py:62
         info = self._info(raw)

@@ -75,14 +75,15 @@ struct agx_ctx {
     int init_r = 0, init_c = 0;
     hipEvent_t prof[2][2] = {{nullptr, nullptr}, {nullptr, nullptr}};   // agx_profile_next: [ingest | fovea][start | stop]
     // Testing knobs, read from the environment ONCE PER CONTEXT in agx_create (so one process can hold contexts of
-    // several forms and compare them).  The shipped library has only the four that select a FALLBACK kernel, i.e. the
-    // kernel other geometries get anyway (tests/test_gpu_parity.py::test_generic_fallback_kernel_matches_tuned); the rest
+    // several forms and compare them).  The shipped library has only the five that select a FALLBACK kernel, i.e. the
+    // kernel (or launch sequence) other geometries get anyway (tests/test_gpu_parity.py::test_generic_fallback_kernel_matches_tuned); the rest
     // exist in the experiments build (-DAGX_EXPERIMENTS, experiments/agx_experiments.h) only.
     struct Tune {
         int generic = 0;         // AGX_FOVEA_GENERIC     K3 / K4 through the generic fallback kernel
         int no_full = 0;         // AGX_INGEST_NO_FULL    general k_ingest<256> even where k_ingest_full12 applies
         int flex_v2 = 0;         // AGX_FLEX_V2           K4 through k_fovea_flexible2 (pass-by-pass form)
         int per_v2 = 0;          // AGX_PER_V2            K3 through k_fovea_peripheral2
+        int packed_unfused = 0;  // AGX_STEP_PACKED_UNFUSED  agx_step_flexible_packed as the three stand-alone launches
         // ---- experiments build only (always 0 in libagx.so)
         int ingest_t = 0;        // AGX_INGEST_T          128 | 256 threads per ingest workgroup
         int band_rows = 0;       // AGX_INGEST_BAND_ROWS  output rows per ingest workgroup (<= the default)
@@ -439,6 +440,7 @@ int agx_create(const agx_config *cfg, agx_ctx **out) {
     ctx->tune.no_full = env_int("AGX_INGEST_NO_FULL");
     ctx->tune.flex_v2 = env_int("AGX_FLEX_V2");
     ctx->tune.per_v2 = env_int("AGX_PER_V2");
+    ctx->tune.packed_unfused = env_int("AGX_STEP_PACKED_UNFUSED");
 #ifdef AGX_EXPERIMENTS
     ctx->tune.ingest_t = env_int("AGX_INGEST_T");
     ctx->tune.band_rows = env_int("AGX_INGEST_BAND_ROWS");
@@ -1366,6 +1368,51 @@ int agx_fovea_flexible(agx_ctx *ctx, const void *d_action, int action_dtype, con
     return AGX_OK;
 }
 
+// the state / scan launch of the packed form (fov_env.py:300-324 + level 1 of the exclusive scan of the crop sizes; the scratch
+// belongs to the context since agx_create)
+static FlexScanParams packed_scan_params(agx_ctx *ctx, const void *d_action, int action_dtype, const int32_t *d_action_type,
+                                         int32_t *d_fov_loc, int32_t *d_fov_res) {
+    FlexScanParams q;
+    q.f = fov_params(ctx, d_action, action_dtype, d_action_type, nullptr, nullptr, d_fov_loc, d_fov_res);
+    q.local_off = ctx->pack_local;
+    q.block_tot = ctx->pack_block;
+    q.n = ctx->cfg.num_envs;
+    q.oh = ctx->cfg.obs_h;
+    q.ow = ctx->cfg.obs_w;
+    return q;
+}
+static bool packed_raw3_ok(const agx_ctx *ctx) { return ctx->fr_ok && ctx->tune.generic == 0 && ctx->tune.flex_v2 == 0; }
+
+// the crop launch of the packed form on the raw3 plan (the state is final: cur_fov has been flipped by the caller)
+static int packed_crops_raw3(agx_ctx *ctx, float *d_packed, int64_t capacity_floats, int64_t *d_offsets, void *stream) {
+    const agx_config &c = ctx->cfg;
+    FovParams p = fov_params(ctx, nullptr, 0, nullptr, nullptr, d_packed, nullptr, nullptr);
+    p.packed = d_packed;
+    p.packed_off = d_offsets;
+    p.packed_cap = capacity_floats;
+    const GeomR gr{c.obs_h, c.obs_w, c.fov_h, c.fov_w};
+    FlexRawParams fr = ctx->fr;
+    fr.local_off = ctx->pack_local;
+    fr.block_tot = ctx->pack_block;
+    fr.offsets = d_offsets;
+    const dim3 grid(c.frame_stack, c.num_envs), block(kThreads);
+    using GS = GeomS<84, 84, 30, 30>;
+#ifdef AGX_EXPERIMENTS
+    if (ctx->tune.packed_wave != 0) {              // one wave per (slot, env) item: measured slower (docs/HISTORY.md, round 4)
+        if (c.obs_h == 84 && c.obs_w == 84 && c.fov_h == 30 && c.fov_w == 30)
+            AGX_LAUNCH(1, (k_fovea_flexible_raw3_wave<GS>), grid, dim3(64), ctx->fr_lds, S(stream), GS{}, fr, p);
+        else
+            AGX_LAUNCH(1, (k_fovea_flexible_raw3_wave<GeomR>), grid, dim3(64), ctx->fr_lds, S(stream), gr, fr, p);
+    } else
+#endif
+    if (c.obs_h == 84 && c.obs_w == 84 && c.fov_h == 30 && c.fov_w == 30)
+        AGX_LAUNCH(1, (k_fovea_flexible_raw3<GS, kRawPacked>), grid, block, ctx->fr_lds, S(stream), GS{}, fr, p);
+    else
+        AGX_LAUNCH(1, (k_fovea_flexible_raw3<GeomR, kRawPacked>), grid, block, ctx->fr_lds, S(stream), gr, fr, p);
+    AGX_HIP(ctx, hipGetLastError());
+    return AGX_OK;
+}
+
 int agx_fovea_flexible_packed(agx_ctx *ctx, const void *d_action, int action_dtype, const int32_t *d_action_type,
                               float *d_packed, int64_t capacity_floats, int64_t *d_offsets, int32_t *d_fov_loc,
                               int32_t *d_fov_res, void *stream) {
@@ -1379,46 +1426,19 @@ int agx_fovea_flexible_packed(agx_ctx *ctx, const void *d_action, int action_dty
     if (rc) return rc;
     DeviceGuard g(c.device);
     // launch 1: every env's new fov_loc / fov_res (fov_env.py:300-324), its crop size, and level 1 of the exclusive scan
-    // (block-local offsets + block totals; the buffers belong to the context since agx_create)
-    FlexScanParams q;
-    q.f = fov_params(ctx, d_action, action_dtype, d_action_type, nullptr, nullptr, d_fov_loc, d_fov_res);
-    q.local_off = ctx->pack_local;
-    q.block_tot = ctx->pack_block;
-    q.n = c.num_envs;
-    q.oh = c.obs_h;
-    q.ow = c.obs_w;
+    // (block-local offsets + block totals)
+    const FlexScanParams q = packed_scan_params(ctx, d_action, action_dtype, d_action_type, d_fov_loc, d_fov_res);
     const int nb = (c.num_envs + kScanEnvsPerBlock - 1) / kScanEnvsPerBlock;
     hipLaunchKernelGGL(k_flex_state_scan, dim3(nb), dim3(kThreads), 0, S(stream), q);
     AGX_HIP(ctx, hipGetLastError());
     ctx->cur_fov ^= 1;                   // the state is final from here on; the crop launch only reads it
     // launch 2: the crops (squeezed to fov_size and back iff rows > fov rows, fov_env.py:283-287) at their offsets
+    if (packed_raw3_ok(ctx)) return packed_crops_raw3(ctx, d_packed, capacity_floats, d_offsets, stream);
     FovParams p = fov_params(ctx, nullptr, 0, nullptr, nullptr, d_packed, nullptr, nullptr);
     p.packed = d_packed;
     p.packed_off = d_offsets;
     p.packed_cap = capacity_floats;
     const GeomR gr{c.obs_h, c.obs_w, c.fov_h, c.fov_w};
-    if (ctx->fr_ok && ctx->tune.generic == 0 && ctx->tune.flex_v2 == 0) {
-        FlexRawParams fr = ctx->fr;
-        fr.local_off = ctx->pack_local;
-        fr.block_tot = ctx->pack_block;
-        fr.offsets = d_offsets;
-        const dim3 grid(c.frame_stack, c.num_envs), block(kThreads);
-        using GS = GeomS<84, 84, 30, 30>;
-#ifdef AGX_EXPERIMENTS
-        if (ctx->tune.packed_wave != 0) {              // one wave per (slot, env) item: measured slower (docs/HISTORY.md, round 4)
-            if (c.obs_h == 84 && c.obs_w == 84 && c.fov_h == 30 && c.fov_w == 30)
-                AGX_LAUNCH(1, (k_fovea_flexible_raw3_wave<GS>), grid, dim3(64), ctx->fr_lds, S(stream), GS{}, fr, p);
-            else
-                AGX_LAUNCH(1, (k_fovea_flexible_raw3_wave<GeomR>), grid, dim3(64), ctx->fr_lds, S(stream), gr, fr, p);
-        } else
-#endif
-        if (c.obs_h == 84 && c.obs_w == 84 && c.fov_h == 30 && c.fov_w == 30)
-            AGX_LAUNCH(1, (k_fovea_flexible_raw3<GS, kRawPacked>), grid, block, ctx->fr_lds, S(stream), GS{}, fr, p);
-        else
-            AGX_LAUNCH(1, (k_fovea_flexible_raw3<GeomR, kRawPacked>), grid, block, ctx->fr_lds, S(stream), gr, fr, p);
-        AGX_HIP(ctx, hipGetLastError());
-        return AGX_OK;
-    }
     // geometries outside the raw3 plan: offsets as a launch of their own, then the pass-by-pass crop kernel, which writes
     // the (unchanged) state through into the other half of the double buffer
     hipLaunchKernelGGL(k_flex_finish_offsets, dim3((c.num_envs + 1 + kThreads - 1) / kThreads), dim3(kThreads), 0, S(stream),
@@ -1441,6 +1461,66 @@ int agx_fovea_flexible_packed(agx_ctx *ctx, const void *d_action, int action_dty
     AGX_HIP(ctx, hipGetLastError());
     ctx->cur_fov ^= 1;
     return AGX_OK;
+}
+
+int agx_step_flexible_packed(agx_ctx *ctx, const uint8_t *d_screens, int screens, const uint8_t *d_cmd, const void *d_action,
+                             int action_dtype, const int32_t *d_action_type, float *d_packed, int64_t capacity_floats,
+                             int64_t *d_offsets, int32_t *d_fov_loc, int32_t *d_fov_res, void *stream) {
+    if (!ctx) return AGX_E_INVALID;
+    const agx_config &c = ctx->cfg;
+    if (c.kind != AGX_KIND_FLEXIBLE || c.out_mode != AGX_OUT_RAW)
+        return fail(ctx, AGX_E_STATE, "agx_step_flexible_packed needs a flexible context in raw-crop mode (kind %d, out_mode %d)",
+                    c.kind, c.out_mode);
+    if (!d_screens || !d_cmd || !d_packed || !d_offsets || capacity_floats < 0)
+        return fail(ctx, AGX_E_INVALID, "agx_step_flexible_packed: null buffer");
+    if (screens & ~(AGX_SCREENS_GRAY | AGX_SCREENS_COMPACT))
+        return fail(ctx, AGX_E_INVALID, "agx_step_flexible_packed: unknown screen layout bits 0x%x", screens);
+    int rc = check_dt(ctx, d_action, action_dtype);
+    if (rc) return rc;
+    const bool gray = (screens & AGX_SCREENS_GRAY) != 0, compact = (screens & AGX_SCREENS_COMPACT) != 0;
+    // the two-launch form needs the band12 ingest plan for this layout and the raw3 crop plan; everything else (and
+    // AGX_STEP_PACKED_UNFUSED=1, for A/B runs) is the three launches of the stand-alone entry points, same results
+    const int br_def = std::max(1, std::min(2 * (kThreads / 40), kThreads / std::max(1, c.obs_w / 4)));
+    bool band12;
+    if (compact) band12 = ctx->compact12_ok && br_def == 12;
+    else if (gray) band12 = ctx->band12_ok && std::min(br_def, ctx->band_rows > 0 && ctx->ingest_t == 256 ? ctx->band_rows : br_def) == 12;
+    else band12 = ctx->band12_ok && ctx->band_rows == 12;
+    const int nb = (c.num_envs + kScanEnvsPerBlock - 1) / kScanEnvsPerBlock;
+    const bool fused = c.obs_h == c.obs_w && band12 && ctx->tune.no_full == 0 && packed_raw3_ok(ctx) && c.num_envs + nb <= 65535 &&
+                       ctx->tune.packed_unfused == 0 && ctx->tune.packed_wave == 0 &&
+                       ctx->tune.pipe_parts == 0 && ctx->tune.wave == 0 && ctx->tune.pair12 == 0 && ctx->ingest_t == 256;
+    if (!fused) {
+        if (compact) rc = gray ? agx_ingest_gray_raw_compact(ctx, d_screens, d_cmd, stream) : agx_ingest_compact(ctx, d_screens, d_cmd, stream);
+        else rc = gray ? agx_ingest_gray_raw(ctx, d_screens, d_cmd, stream) : agx_ingest(ctx, d_screens, d_cmd, stream);
+        if (rc) return rc;
+        return agx_fovea_flexible_packed(ctx, d_action, action_dtype, d_action_type, d_packed, capacity_floats, d_offsets, d_fov_loc,
+                                         d_fov_res, stream);
+    }
+    DeviceGuard g(c.device);
+    IngestParams p = ingest_params(ctx, d_screens, d_cmd);
+    p.band_rows = 12;
+    p.nbands = c.obs_h / 12;
+    if (compact) {
+        p.src_rows = (int32_t)ctx->src_rows.size();
+        p.ytab = ctx->in_ytab_c;
+        p.y_affine = 0;
+    }
+    const FlexScanParams q = packed_scan_params(ctx, d_action, action_dtype, d_action_type, d_fov_loc, d_fov_res);
+    // launch 1: the scan blocks (first rows of the grid) + the ingest bands
+    const dim3 grid(p.nbands, nb + c.num_envs), block(kThreads);
+    const size_t lds = band12_lds(ctx);
+    if (compact) {
+        if (gray) AGX_LAUNCH(0, (k_ingest_full12_flexscan<true, true>), grid, block, lds, S(stream), p, q, nb);
+        else AGX_LAUNCH(0, (k_ingest_full12_flexscan<false, true>), grid, block, lds, S(stream), p, q, nb);
+    } else {
+        if (gray) AGX_LAUNCH(0, (k_ingest_full12_flexscan<true, false>), grid, block, lds, S(stream), p, q, nb);
+        else AGX_LAUNCH(0, (k_ingest_full12_flexscan<false, false>), grid, block, lds, S(stream), p, q, nb);
+    }
+    AGX_HIP(ctx, hipGetLastError());
+    ctx->cur_head ^= 1;
+    ctx->cur_fov ^= 1;
+    // launch 2: the crops
+    return packed_crops_raw3(ctx, d_packed, capacity_floats, d_offsets, stream);
 }
 
 }  // extern "C"

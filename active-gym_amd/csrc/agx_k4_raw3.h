@@ -53,11 +53,11 @@ struct FlexScanParams {
     int64_t *block_tot;
     int32_t n, oh, ow;
 };
-__global__ __launch_bounds__(kThreads) void k_flex_state_scan(FlexScanParams q) {
-    __shared__ int64_t wave_tot[kThreads / 64];
+// one scan block (256 envs, one per thread); wave_tot: kThreads / 64 int64 of this workgroup's LDS
+__device__ __forceinline__ void flex_state_scan_block(const FlexScanParams &q, const int block, int64_t *wave_tot) {
     const FovParams &p = q.f;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int n = blockIdx.x * kScanEnvsPerBlock + tid;
+    const int n = block * kScanEnvsPerBlock + tid;
     int64_t mine = 0;
     if (n < q.n) {
         const LocIn lin = load_loc_inputs(p, n);
@@ -91,7 +91,11 @@ __global__ __launch_bounds__(kThreads) void k_flex_state_scan(FlexScanParams q) 
     for (int w = 0; w < kThreads / 64; ++w)
         if (w < wave) before += wave_tot[w];
     if (n < q.n) q.local_off[n] = before + incl - mine;
-    if (tid == kThreads - 1) q.block_tot[blockIdx.x] = before + incl;
+    if (tid == kThreads - 1) q.block_tot[block] = before + incl;
+}
+__global__ __launch_bounds__(kThreads) void k_flex_state_scan(FlexScanParams q) {
+    __shared__ int64_t wave_tot[kThreads / 64];
+    flex_state_scan_block(q, blockIdx.x, wave_tot);
 }
 
 // fallback of the packed form for geometries outside the raw3 plan: offsets[] from the two scan levels (grid = ceil((N+1)/256))

@@ -23,6 +23,7 @@
 #include "agx_k3_per3.h"
 #include "agx_k4_flex3.h"
 #include "agx_k4_raw3.h"
+#include "agx_k14_step_packed.h"
 #ifdef AGX_EXPERIMENTS
 #include "experiments/agx_experiments.h"   // measured dead ends: tools/ and the variants test only, never in libagx.so
 #include "experiments/agx_packed_wave.h"

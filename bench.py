@@ -49,6 +49,9 @@ def parse():
     ap.add_argument("--out", default="full", choices=("full", "packed"),
                     help="flexible kind: full = resize_to_full (the config-4 workload); packed = the ragged raw-crop sub-run "
                          "(agx_fovea_flexible_packed: [fs, rh, rw] crops packed back to back + offsets)")
+    ap.add_argument("--packed-calls", type=int, default=1, choices=(1, 2),
+                    help="--out packed: 1 = the whole step as agx_step_flexible_packed (two launches: the state update + scan ride in "
+                         "the ingest launch); 2 = agx_ingest + agx_fovea_flexible_packed (three launches), for A/B runs")
     ap.add_argument("--preroll", type=int, default=1000,
                     help="untimed steps run BEFORE the warmup so that a short run (the driver's --steps 20) is not timed on the "
                          "first milliseconds of an idle device (clock ramp); not part of `warmup` or `steps`")
@@ -102,7 +105,8 @@ def workload_name(args, n, packed_mode, gray, compact):
     which = {"fixed": ("AtariFixedFovealEnv", "configs[1]"), "peripheral": ("AtariFixedFovealPeripheralEnv, peripheral_res 20x20", "configs[2]"),
              "flexible": ("AtariFlexibleFovealEnv, per-env fov_res in [10,60]^2, 50% FOV_RES actions", "configs[3]")}[args.kind]
     s = f"{n}x {which[0]} per GPU, 84x84 obs, 30x30 fov, frame_stack=4, action_repeat=4, "
-    s += "ragged raw crops packed (agx_fovea_flexible_packed)" if packed_mode else "resize_to_full"
+    s += (("ragged raw crops packed (agx_step_flexible_packed: ingest + state / scan in one launch, crops in the second)" if args.packed_calls == 1 else
+           "ragged raw crops packed (agx_ingest + agx_fovea_flexible_packed: three launches)") if packed_mode else "resize_to_full")
     if args.kind != "fixed":
         s += f", antialias={args.antialias}"
     s += ", absolute sensory actions; "
@@ -521,6 +525,14 @@ def main():
             e = None
         if e is not None:
             e[0].record()
+        if packed_mode and args.packed_calls == 1:
+            # the whole step in one ABI call and two launches (the layout is read off the screens' shape)
+            pipe.step_flexible_packed(state["frames"][i], cmds[i], acts[i], action_type=types[i], packed=packed_buf, offsets=offsets,
+                                      loc_out=loc, res_out=res_out)
+            if e is not None:
+                e[1].record()
+                e[2].record()
+            return
         state["ingest"](state["frames"][i], cmds[i])
         if e is not None:
             e[1].record()
@@ -677,7 +689,9 @@ def main():
                        "input_layout": ("compact screens u8 [N,2,%d,160,%s]: the rows K1 reads, as the host runner stages them (agx_ingest_compact)"
                                         % (int(src_rows.numel()), "1" if gray else "3")) if use_compact else
                                        "whole screens u8 [N,2,210,160,%s]" % ("1" if gray else "3"),
-                       "step_form": "two stand-alone launches per step",
+                       "step_form": ("two stand-alone launches per step" if not packed_mode else
+                                     "two launches per step (ingest + state / scan | crops)" if args.packed_calls == 1 else
+                                     "three launches per step (ingest | state / scan | crops)"),
                        "parallelism": f"env-shard x{world}, no collective"},
             "roofline": roof, "kernels": kernels, "build": _build_info(),
             "per_gpu": [n * K / t_ for t_ in per_rank], "per_gpu_unit": "env steps/s of each rank over its own timed region",

@@ -254,6 +254,23 @@ AGX_API int agx_fovea_flexible_packed(agx_ctx *ctx, const void *d_action, int ac
                                       float *d_packed, int64_t capacity_floats, int64_t *d_offsets, int32_t *d_fov_loc,
                                       int32_t *d_fov_res, void *stream);
 
+/* One whole step of such a context - agx_ingest* followed by agx_fovea_flexible_packed (atari_env.py:119-148, then
+ * fov_env.py:300-330, 283-298) - as ONE call and TWO launches: the state update + scan reads the actions and the old fov state and
+ * nothing the ingest writes, so its ceil(N / 256) workgroups ride in the ingest launch (first rows of its grid) instead of costing a
+ * launch of their own (4.9 us of 49 at N = 1024).  Same results as the two calls, bit for bit.
+ *   d_screens / screens : the two sampled screens of every env in the layout `screens` names: 0 = whole RGB screens as agx_ingest
+ *                         takes them, AGX_SCREENS_GRAY = ALE grayscale screens (agx_ingest_gray_raw), | AGX_SCREENS_COMPACT = only the
+ *                         rows agx_source_rows lists (agx_ingest_compact / agx_ingest_gray_raw_compact)
+ *   the rest            : as agx_ingest (d_cmd) and agx_fovea_flexible_packed
+ * Geometries without the headline ingest plan (12-row bands) or crop plan take the three launches of the stand-alone entry
+ * points inside this call (AGX_STEP_PACKED_UNFUSED=1 forces that, for A/B runs). */
+#define AGX_SCREENS_GRAY 1
+#define AGX_SCREENS_COMPACT 2
+AGX_API int agx_step_flexible_packed(agx_ctx *ctx, const uint8_t *d_screens, int screens, const uint8_t *d_cmd,
+                                     const void *d_action, int action_dtype, const int32_t *d_action_type, float *d_packed,
+                                     int64_t capacity_floats, int64_t *d_offsets, int32_t *d_fov_loc, int32_t *d_fov_res,
+                                     void *stream);
+
 #ifdef __cplusplus
 }
 #endif

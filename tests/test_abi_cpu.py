@@ -24,7 +24,7 @@ def _declared():
 
 def test_header_declares_the_expected_surface():
     names = _declared()
-    assert len(names) == 27 and "agx_ingest" in names and "agx_ingest_compact" in names and "agx_source_rows" in names and "agx_fovea_flexible" in names
+    assert len(names) == 28 and "agx_step_flexible_packed" in names and "agx_ingest" in names and "agx_ingest_compact" in names and "agx_source_rows" in names and "agx_fovea_flexible" in names
 
 
 def test_library_exports_every_declared_symbol():
