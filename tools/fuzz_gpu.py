@@ -118,7 +118,16 @@ def one_case(k):
             a = np.where(types[:, None] == 1, np.stack([rng.integers(1, oh + 1, N), rng.integers(1, ow + 1, N)], 1),
                          np.stack([rng.integers(-5, oh + 5, N), rng.integers(-5, ow + 5, N)], 1)).astype(np.int64)
             if packed_case:
-                flat, off, loc_t, res_t = p.fovea_packed(t(a), action_type=t(types))
+                if oh == ow and rng.random() < 0.5:
+                    # the whole step as one call (agx_step_flexible_packed: the state / scan blocks ride in the ingest launch where the
+                    # geometry has the band12 plan, three launches inside the call otherwise) with every env's command = SKIP, so
+                    # that the ring set above stands and the crops must be what agx_fovea_flexible_packed gives on it
+                    cfg["one_call"] = True
+                    gray = rng.random() < 0.5
+                    scr = rng.integers(0, 256, (N, 2, 210, 160) + (() if gray else (3,)), dtype=np.uint8)
+                    flat, off, loc_t, res_t = p.step_flexible_packed(t(scr), t(np.full(N, 8, np.uint8)), t(a), action_type=t(types))
+                else:
+                    flat, off, loc_t, res_t = p.fovea_packed(t(a), action_type=t(types))
                 flat, off, res_n = flat.cpu().numpy(), off.cpu().numpy(), res_t.cpu().numpy()
                 assert off[0] == 0 and np.array_equal(np.diff(off), fs * res_n[:, 0].astype(np.int64) * res_n[:, 1]), (cfg, step)
                 pad = np.zeros((N, fs, oh, ow), np.float32)
