@@ -36,6 +36,52 @@ def _resolve_antialias(args):
     return bool(getattr(args, "antialias", True))
 
 
+class _HostObsPool:
+    """Fresh-array semantics for host (NumPy) observations at pinned-buffer cost.
+
+    The reference's envs hand out a new array per call (atari_env.py:143 ``np.stack``), so a caller may keep any of them.  A
+    device-to-PAGEABLE copy into a fresh 115 MB array costs 30+ ms per step at N = 1024 (page faults of the fresh mapping +
+    the staged copy); a copy into PINNED memory 2 ms.  The pool hands out NumPy views of pinned buffers and takes a buffer back
+    only when the array it handed out - and every view derived from it - has been garbage collected (``weakref.finalize`` on
+    the array: derived views keep their base alive).  A caller that drops its observations as it goes (the usual loop) cycles
+    through 2-3 buffers; one that keeps them all gets ``max_buffers`` pinned ones and ordinary pageable arrays after that.
+    """
+
+    def __init__(self, max_buffers: int):
+        import collections
+        self.max_buffers = int(max_buffers)
+        self._free = collections.deque()         # append / pop are atomic: finalizers may run on any thread
+        self._made = 0
+        self._shape = None
+
+    def take(self, shape, dtype):
+        """A pinned tensor no array refers to, or None (budget spent: the caller falls back to a pageable array)."""
+        shape = tuple(shape)
+        if self._shape != (shape, dtype):       # another observation shape: start over (outstanding arrays keep their buffers)
+            self._free.clear()
+            self._made = 0
+            self._shape = (shape, dtype)
+        try:
+            return self._free.pop()
+        except IndexError:
+            pass
+        if self._made >= self.max_buffers:
+            return None
+        self._made += 1
+        return torch.empty(shape, dtype=dtype, pin_memory=True)
+
+    def hand_out(self, buf: torch.Tensor) -> np.ndarray:
+        import weakref
+        arr = buf.numpy()
+        key = self._shape
+        weakref.finalize(arr, self._give_back, buf, key).atexit = False      # nothing to recycle at interpreter shutdown
+        return arr
+
+    def _give_back(self, buf, key):
+        if key == self._shape:
+            self._free.append(buf)
+
+
 class AtariVecEnv:
     """N envs of one kind.  ``args`` is an ``AtariEnvArgs``; extra optional attributes:
     ``frame_source`` ("ale" | "synthetic" | factory), ``device`` (None -> NumPy outputs on the host like
@@ -145,13 +191,16 @@ class AtariVecEnv:
         # step after next without a 115 MB clone per step (args.copy_obs=True restores a fresh tensor per call)
         shp = self.pipe.obs_shape if kind != "base" else self.pipe.full_shape
         self._copy_obs = bool(getattr(self.args, "copy_obs", False))
-        # Host (NumPy) outputs: a fresh array per call by default, like the reference's envs - which costs a device-to-PAGEABLE copy
-        # of the whole observation batch per step (115 MB at N = 1024: 24 ms, against 2 ms for everything else).  args.copy_obs =
-        # False (gymnasium's SyncVectorEnv(copy=False)) returns views of two PINNED host buffers used alternately instead (4 ms):
-        # an observation then stays valid until the step after next, as with device outputs.
+        # Host (NumPy) outputs: a fresh array per call by default, like the reference's envs.  args.copy_obs = False (gymnasium's
+        # SyncVectorEnv(copy=False)) returns views of two PINNED host buffers used alternately instead (4 ms at N = 1024): an
+        # observation then stays valid until the step after next, as with device outputs.
         self._pinned_host_obs = self._numpy_out and getattr(self.args, "copy_obs", True) is False
         self._h_obs = None
         self._h_obs_i = 0
+        # ... and the default itself: fresh-array SEMANTICS from a pool of pinned buffers that are recycled once the caller has
+        # dropped the array (_HostObsPool; args.host_obs_buffers = 0 restores the pageable copy per call)
+        nbuf = getattr(self.args, "host_obs_buffers", 4)
+        self._host_pool = _HostObsPool(int(nbuf)) if (self._numpy_out and not self._pinned_host_obs and int(nbuf or 0) > 0) else None
         self._obs_bufs = [torch.empty(shp, dtype=torch.float32, device=self.device)
                           for _ in range(1 if (self._numpy_out or self._copy_obs) else 2)]
         self._obs_i = 0
@@ -464,6 +513,12 @@ class AtariVecEnv:
             h.copy_(obs, non_blocking=True)
             torch.cuda.current_stream(self.device).synchronize()
             return h.numpy()
+        if self._numpy_out and self._host_pool is not None:
+            h = self._host_pool.take(obs.shape, obs.dtype)
+            if h is not None:
+                h.copy_(obs, non_blocking=True)
+                torch.cuda.current_stream(self.device).synchronize()
+                return self._host_pool.hand_out(h)
         if self._numpy_out:
             return self._out(obs)
         return obs.clone() if self._copy_obs else obs

@@ -991,6 +991,56 @@ def test_host_outputs_through_pinned_buffers_equal_fresh_copies():
     b.close()
 
 
+def test_default_host_outputs_are_fresh_arrays_from_recycled_pinned_buffers():
+    """Default host (NumPy) outputs: every call hands out an array of its own, as the reference's envs do (atari_env.py:143) - kept
+    arrays never change, however many the caller keeps (beyond `host_obs_buffers` they are ordinary pageable arrays) - and a
+    caller that drops its observations gets the pinned buffers back (the same few addresses recur).  Same values as with the pool
+    switched off."""
+    import gc
+    from active_gym import AtariEnvArgs, AtariVecEnv
+    N = 6
+    kw = dict(game="g", seed=9, obs_size=(84, 84), fov_size=(30, 30), fov_init_loc=(0, 0), sensory_action_mode="absolute", resize_to_full=True,
+              frame_source="native", scripted_actions=4, scripted_lives=2, scripted_p_life=80, scripted_p_over=20, num_workers=2)
+    a = AtariVecEnv(AtariEnvArgs(host_obs_buffers=0, **kw), N, kind="fixed", noop_fn=lambda: 1)       # pageable copy per call
+    b = AtariVecEnv(AtariEnvArgs(host_obs_buffers=3, **kw), N, kind="fixed", noop_fn=lambda: 1)
+    assert a._host_pool is None and b._host_pool is not None
+    oa, ob = a.reset()[0], b.reset()[0]
+    assert isinstance(ob, np.ndarray) and ob.dtype == np.float32 and np.array_equal(oa, ob)
+    rng = np.random.default_rng(2)
+    kept = [(ob, ob.copy())]
+    for step in range(9):                       # keep EVERYTHING: three pinned buffers, then pageable arrays
+        act = {"motor_action": rng.integers(0, 4, N), "sensory_action": rng.uniform(-5, 60, (N, 2))}
+        ra, rb = a.step(act), b.step(act)
+        assert np.array_equal(ra[0], rb[0]) and np.array_equal(ra[1], rb[1]) and np.array_equal(ra[2], rb[2]), step
+        kept.append((rb[0], rb[0].copy()))
+        for i in np.nonzero(ra[2])[0]:
+            assert np.array_equal(ra[4]["final_observation"][i], rb[4]["final_observation"][i])
+    assert len({k[0].ctypes.data for k in kept}) == len(kept), "every kept observation has memory of its own"
+    for k, (arr, copy) in enumerate(kept):
+        assert np.array_equal(arr, copy), f"observation {k} changed while the caller held it"
+    assert b._host_pool._made == 3
+    # a view keeps its buffer out of the pool; dropping everything returns the three pinned buffers, and they are what recurs
+    row = kept[1][0][2]
+    del kept, ra, rb, oa, ob, arr, copy
+    gc.collect()
+    assert len(b._host_pool._free) == 2
+    want_row = row.copy()
+    seen = set()
+    for step in range(8):
+        act = {"motor_action": rng.integers(0, 4, N), "sensory_action": rng.uniform(-5, 60, (N, 2))}
+        a.step(act)
+        o = b.step(act)[0]
+        seen.add(o.ctypes.data)
+        del o
+    assert len(seen) <= 2 and b._host_pool._made == 3
+    assert np.array_equal(row, want_row)
+    del row
+    gc.collect()
+    assert len(b._host_pool._free) == 3
+    a.close()
+    b.close()
+
+
 @pytest.mark.parametrize("fmt", ["rgb", "gray"])
 def test_native_loop_running_ahead_of_the_device_matches_a_synchronous_run(fmt):
     """The step loop never synchronises the device: the host runs up to two steps ahead, emulators overwrite one pinned staging set

@@ -122,3 +122,36 @@ def test_every_device_entry_point_opens_a_device_guard():
             first = touches.start()
             guard = text.find("DeviceGuard g(")
             assert 0 <= guard < first or (delegates and guard < 0 and name == "agx_step_fixed"), name
+
+
+def test_host_observation_pool_recycles_only_unreferenced_buffers(monkeypatch):
+    """active_gym/vector.py::_HostObsPool - the logic behind the default host (NumPy) outputs, without pinning (no GPU here): a
+    buffer comes back only when the array handed out AND every view of it are gone; the budget caps the pinned buffers; another
+    observation shape starts a new pool and stray give-backs of the old shape are ignored."""
+    import gc
+    import torch
+    import active_gym.vector as v
+    real_empty = torch.empty
+    monkeypatch.setattr(v.torch, "empty", lambda shape, dtype=None, pin_memory=False: real_empty(shape, dtype=dtype))
+    pool = v._HostObsPool(2)
+    a = pool.hand_out(pool.take((4, 3), torch.float32))
+    b = pool.hand_out(pool.take((4, 3), torch.float32))
+    assert a.shape == (4, 3) and a.ctypes.data != b.ctypes.data
+    assert pool.take((4, 3), torch.float32) is None                     # budget spent: the env falls back to a pageable array
+    addr = a.ctypes.data
+    view = a[1:]
+    del a
+    gc.collect()
+    assert pool.take((4, 3), torch.float32) is None                     # the view keeps the buffer out
+    del view
+    gc.collect()
+    t = pool.take((4, 3), torch.float32)
+    assert t is not None and t.data_ptr() == addr
+    c = pool.hand_out(t)
+    # another shape: a new pool of its own budget; the old arrays stay valid and their late give-backs are dropped
+    d = pool.hand_out(pool.take((2, 2), torch.float32))
+    b[:] = 7
+    del c
+    gc.collect()
+    assert len(pool._free) == 0 and pool._made == 1
+    assert float(b.sum()) == 7 * 12 and d.shape == (2, 2)
