@@ -497,6 +497,9 @@ class AtariVecEnv:
         self._obs_i = (self._obs_i + 1) % len(self._obs_bufs)
         self._obs = self._obs_bufs[self._obs_i]
 
+    # below 1 MB of observations (the single-env wrappers: 113 KB) a pageable copy is as cheap as the pool's bookkeeping
+    _HOST_POOL_MIN_ELEMS = 1 << 18
+
     def _ret_obs(self, obs):
         if self._ragged_packed:
             off = self._poff.cpu().numpy()
@@ -513,7 +516,7 @@ class AtariVecEnv:
             h.copy_(obs, non_blocking=True)
             torch.cuda.current_stream(self.device).synchronize()
             return h.numpy()
-        if self._numpy_out and self._host_pool is not None:
+        if self._numpy_out and self._host_pool is not None and obs.numel() >= self._HOST_POOL_MIN_ELEMS:
             h = self._host_pool.take(obs.shape, obs.dtype)
             if h is not None:
                 h.copy_(obs, non_blocking=True)

@@ -998,7 +998,7 @@ def test_default_host_outputs_are_fresh_arrays_from_recycled_pinned_buffers():
     switched off."""
     import gc
     from active_gym import AtariEnvArgs, AtariVecEnv
-    N = 6
+    N = 12                                      # 12 x 4 x 84 x 84 floats: above the pool's 1 MB threshold (smaller batches are copied pageable)
     kw = dict(game="g", seed=9, obs_size=(84, 84), fov_size=(30, 30), fov_init_loc=(0, 0), sensory_action_mode="absolute", resize_to_full=True,
               frame_source="native", scripted_actions=4, scripted_lives=2, scripted_p_life=80, scripted_p_over=20, num_workers=2)
     a = AtariVecEnv(AtariEnvArgs(host_obs_buffers=0, **kw), N, kind="fixed", noop_fn=lambda: 1)       # pageable copy per call
