@@ -2,7 +2,7 @@
 """Soak: AtariVecEnv on the native runner for a time budget per configuration, with episode ends (autoreset) in every step - host RSS, device
 memory in use (hipMemGetInfo through torch) and steps/s sampled along the way.  A step call allocates nothing on the native loop and only
 its outputs' Python objects on the Python loop, so all three must be flat.  The baseline is taken after 1,500 warm-up steps: the first
-few hundred steps of the first env of a process grow its RSS once by ~190 MB under either step loop - not in the malloc arena (mallinfo2
+few hundred steps of the first env of a process grow its RSS by ~190 MB once or twice (the second increment has been seen as late as 20 k steps in: profiles/r04_soak_final_tree.txt) under either step loop - not in the malloc arena (mallinfo2
 stays flat, profiles/r04_soak_heap_stats.txt: a mapping of the HIP runtime's own), not repeated by a second env in the same process -
 printed as "warm-up", not counted as growth.
 
