@@ -47,6 +47,10 @@ def one_case(k):
                         device="cuda:0" if on_device else None, native_loop=native_loop, compact_rows=compact,
                         scripted_actions=n_act, scripted_lives=lives, scripted_p_life=p_life, scripted_p_over=p_over, **kw)
     env = AtariVecEnv(args, N, kind=kind, noop_fn=lambda: int(next(it_a)))
+    if not on_device and rng.random() < 0.5:
+        # host outputs through the recycled pinned pool whatever the batch size (the product uses it from 1 MB of observations up)
+        env._HOST_POOL_MIN_ELEMS = 0
+        cfg["host_pool"] = True
     if not training:
         env.eval()
     chains = []
@@ -95,7 +99,10 @@ def one_case(k):
         act = motor if kind == "base" else {"motor_action": motor, "sensory_action": sens}
         if kind == "flexible":
             act["sensory_action_type"] = types
+        held = (obs, np.array(obs, copy=True)) if cfg.get("host_pool") and isinstance(obs, np.ndarray) else None
         obs, rew, term, trunc, infos = env.step(act)
+        if held is not None:                     # an observation the caller still holds is never overwritten by a later step
+            assert np.array_equal(held[0], held[1]), (cfg, step, "a held observation changed")
         for key in ("fov_loc", "fov_res"):
             if key in infos:
                 infos[key] = npy(infos[key])
