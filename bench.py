@@ -676,6 +676,10 @@ def main():
                 roof["traffic"] = tr["traffic"]
                 roof["traffic_unit"] = "bytes per launch"
                 roof["traffic_source"] = tr["note"]
+                # the same launch priced on the bytes it actually moved (PMC) instead of the algorithmic ones: how close the kernel
+                # runs to what the memory system streams at all; `frac` above stays the algorithmic figure
+                roof["traffic_frac"] = tr["traffic"] / (kernels[dom]["avg_us"] * 1e-6) / 1e9 / HBM_PEAK_GBS
+                roof["traffic_over_algorithmic"] = tr["traffic"] / kernels[dom]["algorithmic_bytes"]
             else:
                 roof["traffic_source"] = why
         out = {
