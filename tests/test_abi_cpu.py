@@ -108,3 +108,18 @@ def test_loop_header_surface_is_exported_and_bound():
     hdr = open(os.path.join(REPO, "include", "agx_runner.h")).read()
     assert "agxr_step(agxr_runner *r, const int32_t *motor, uint8_t *frames, uint8_t *cmd, double *reward,\n" in hdr.replace("AGXR_API int ", "")
     assert "agxr_reset_packed(agxr_runner *r, const int32_t *idx, int32_t k, const int32_t *noops, uint8_t *frames,\n" in hdr.replace("AGXR_API int ", "")
+
+
+def test_binding_constants_mirror_the_header():
+    """Every numeric `#define AGX_<NAME> <value>` of include/agx.h has a twin `<NAME>` in active_gym/_native.py with the same value
+    (a constant changed on one side only would mis-drive the kernels silently)."""
+    from active_gym import _native as nat
+    src = open(os.path.join(REPO, "include", "agx.h")).read()
+    found = 0
+    for name, val in re.findall(r"^#define\s+AGX_([A-Z0-9_]+)\s+(-?(?:0x[0-9A-Fa-f]+|\d+))\b", src, flags=re.M):
+        if name in ("H", "CMD_NVALID_MASK"):
+            continue
+        assert hasattr(nat, name), f"active_gym/_native.py lacks {name}"
+        assert getattr(nat, name) == int(val, 0), (name, getattr(nat, name), val)
+        found += 1
+    assert found >= 30
